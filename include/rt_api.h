@@ -1,0 +1,162 @@
+/*
+ * rt_api.h -- C ABI of librt_amd.so: the MI355X (gfx950) implementation of the per-pixel
+ * render path of elliot-chung/raytracer.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the
+ * reference's src/).  Conventions:
+ *  - every function returns 0 on success, a negative rt_status otherwise, and never calls
+ *    exit() (the reference's checkCudaErrors does: helper_cuda.h:583-595);
+ *    rt_last_error(ctx) returns the message of the last failure on that context;
+ *  - handles are small non-negative integers scoped to their context;
+ *  - one context per GPU, driven by one host thread at a time (the reference is single
+ *    threaded and synchronous: processor/GPU/GPURaytracer.cu:65-66);
+ *  - matrices are 16 floats, column-major, exactly linal.hpp:5-9 (mat4transfer);
+ *  - framebuffers are float4 RGBA32F, row 0 = bottom row of the picture (Camera.hpp:65).
+ */
+#ifndef RT_API_H
+#define RT_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+typedef int32_t rt_id;
+
+enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,   /* bad argument / handle */
+    RT_ERR_HIP = -2,       /* a HIP runtime call failed; message names it */
+    RT_ERR_NO_DEVICE = -3, /* no usable gfx950 device */
+    RT_ERR_STATE = -4      /* call order (e.g. render before commit) */
+};
+
+/* processor/GPU/GPURaytracer.hpp:60-69 (CameraParams; the ray texture is set separately) */
+typedef struct {
+    float origin[4];
+    float rotation[4]; /* quaternion x,y,z,w */
+    float exposure;
+    int32_t width;
+    int32_t height;
+} rt_camera_params;
+
+/* processor/GPU/GPURaytracer.hpp:78-87 (RendererParams) */
+typedef struct {
+    int32_t bounceCount;
+    float maxDistance;
+    float aoIntensity;
+    uint32_t frameCount;
+    uint32_t progressiveFrameCount;
+    int32_t antiAliasingEnabled;
+    uint32_t sampleCount;
+} rt_renderer_params;
+
+/* processor/GPU/GPURaytracer.hpp:71-76 (SkyLightParams) */
+typedef struct {
+    float direction[4];
+    float lightColor[4];
+    float skyColor[4];
+} rt_sky_params;
+
+typedef struct { int32_t x0, y0, x1, y1; } rt_rect; /* half-open pixel rectangle (image tile) */
+
+/* Material.hpp:53-77 (GPUMaterial) as Material::sendToGPU fills it (Material.cu:30-49) */
+typedef struct {
+    float albedo[4];
+    float roughness;
+    float metal;
+    float emissionColor[3];
+    float emissionStrength;
+    rt_id texNormal, texAlbedo, texRoughness, texMetal; /* -1 = none */
+} rt_material_desc;
+
+typedef struct {
+    uint64_t rays;         /* closest-hit queries (GPURaytracer.cu:247 calls) of the last rt_render */
+    float    kernel_ms;    /* HIP-event duration of the last rt_render's kernel(s) on the ctx stream */
+    uint32_t triangles;    /* flattened world-space triangles of the committed scene */
+    uint32_t bvh_nodes;    /* nodes of the committed acceleration structure */
+    float    commit_ms;    /* device time of the last rt_scene_commit */
+    uint64_t slow_path;    /* rays that took the exact in-order fallback in the last rt_render */
+    uint64_t node_visits;  /* BVH node visits of the last rt_render (0 unless RT_OPT_COUNTERS) */
+    uint64_t tri_tests;    /* triangle tests of the last rt_render (0 unless RT_OPT_COUNTERS) */
+} rt_stats;
+
+enum rt_option {
+    RT_OPT_TRAVERSAL = 1, /* 0 = BVH (default), 1 = brute force in reference order */
+    RT_OPT_COUNTERS = 2   /* 1 = count node visits / triangle tests (slower) */
+};
+
+/* ---- context ---- */
+int rt_ctx_create(int device, rt_ctx** out);
+int rt_ctx_destroy(rt_ctx* ctx);
+const char* rt_last_error(const rt_ctx* ctx); /* ctx may be NULL: last error of a failed rt_ctx_create */
+int rt_set_stream(rt_ctx* ctx, void* hip_stream); /* NULL = the context's own stream */
+int rt_set_option(rt_ctx* ctx, int option, int value);
+int rt_sync(rt_ctx* ctx);                     /* replaces cudaDeviceSynchronize, GPURaytracer.cu:66 */
+int rt_get_stats(rt_ctx* ctx, rt_stats* out);
+
+/* ---- scene upload ---- */
+/* Mesh::Mesh (Mesh.hpp:30-62): pos 3*nVerts, idx 3*nTris, uv 2*nVerts or NULL, nrm 3*nVerts or NULL */
+int rt_mesh_create(rt_ctx* ctx, const float* pos, int32_t nVerts, const int32_t* idx, int32_t nTris,
+                   const float* uv, const float* nrm, rt_id* out);
+int rt_mesh_destroy(rt_ctx* ctx, rt_id mesh);
+/* Texture::Texture (Material.cu:162-232) after decode + 4-channel expansion: rgba8, row 0 first */
+int rt_texture_create(rt_ctx* ctx, const uint8_t* rgba8, int32_t width, int32_t height, rt_id* out);
+int rt_texture_destroy(rt_ctx* ctx, rt_id texture);
+/* Material::sendToGPU (Material.cu:30-49) */
+int rt_material_create(rt_ctx* ctx, const rt_material_desc* desc, rt_id* out);
+int rt_material_update(rt_ctx* ctx, rt_id material, const rt_material_desc* desc);
+int rt_material_destroy(rt_ctx* ctx, rt_id material);
+/* DisplayObject::sendToGPU (DisplayObject.cpp:30-81): mesh list, per-mesh material index,
+ * material list, composite bounds in object space */
+int rt_object_create(rt_ctx* ctx, const rt_id* meshes, const int32_t* materialIndices, int32_t nMeshes,
+                     const rt_id* materials, int32_t nMaterials, const float bmin[3], const float bmax[3],
+                     rt_id* out);
+int rt_object_destroy(rt_ctx* ctx, rt_id object);
+/* Scene::getGPUObjectDataVector (Scene.cpp:3-29): instance table in iteration order; flattens
+ * the instances to world space and (re)builds the acceleration structure on the GPU */
+int rt_scene_commit(rt_ctx* ctx, const rt_id* objects, const float* model16, const float* invModel16, int32_t n);
+
+/* Camera::calcRays upload (Camera.hpp:73-102): W*H float4 pre-rotation directions (host memory) */
+int rt_camera_set_rays(rt_ctx* ctx, const float* rays4, int32_t width, int32_t height);
+
+/* ---- output (replaces the CUDA-GL surface, RenderWindow.cpp:215-234) ---- */
+int rt_framebuffer_create(rt_ctx* ctx, int32_t width, int32_t height, rt_id* out);
+/* wrap caller-owned device memory (e.g. a torch tensor) of width*height float4 */
+int rt_framebuffer_wrap(rt_ctx* ctx, void* device_ptr, int32_t width, int32_t height, rt_id* out);
+int rt_framebuffer_destroy(rt_ctx* ctx, rt_id fb);
+int rt_framebuffer_read(rt_ctx* ctx, rt_id fb, float* host_rgba);         /* synchronises */
+int rt_framebuffer_write(rt_ctx* ctx, rt_id fb, const float* host_rgba);  /* seed progressive state */
+/* hit-id AOV: 4 uint32 per pixel = object, mesh, triangle of sample 0's primary hit
+ * (0xFFFFFFFF = miss) and a checksum over every path segment of every sample */
+int rt_framebuffer_enable_ids(rt_ctx* ctx, rt_id fb, int enable);
+int rt_framebuffer_read_ids(rt_ctx* ctx, rt_id fb, uint32_t* host_ids);
+
+/* GPURaytracer::raytrace (GPURaytracer.cu:24-74): one frame of `tile` into fb; asynchronous on
+ * the context stream (rt_sync / rt_framebuffer_read wait).  frameCount bookkeeping stays with
+ * the caller exactly as Raytracer keeps it (Raytracer.hpp:49-50, GPURaytracer.cu:69-73). */
+int rt_render(rt_ctx* ctx, const rt_camera_params* camera, const rt_renderer_params* renderer,
+              const rt_sky_params* sky, rt_rect tile, rt_id fb);
+
+/* closest-hit queries for caller-supplied rays (GPURaytracer.cu:247-265 semantics).
+ * rays: 8 floats each (origin xyz, maxDistance, direction xyz, pad); out: 4 uint32 each
+ * (object, mesh, triangle, float bits of t; all 0xFFFFFFFF on miss).  Host pointers. */
+int rt_trace_rays(rt_ctx* ctx, const float* rays, int32_t nRays, uint32_t* out);
+
+/* HIP-event timing on the context stream: record into slot 0..15, elapsed between two slots */
+int rt_event_record(rt_ctx* ctx, int slot);
+int rt_event_elapsed_ms(rt_ctx* ctx, int slot_begin, int slot_end, float* ms);
+
+/* test tap: evaluate the pinned device math on n host floats.
+ * op: 0 log, 1 cos, 2 exp, 3 pow(x,5), 4 pow(x,1000), 5 rsqrt, 6 random_value(seed bits) */
+int rt_detmath_eval(rt_ctx* ctx, int op, const float* in, int32_t n, float* out);
+
+const char* rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,113 @@
+// rt_device.h -- device data model of librt_amd (HBM layout).
+//
+// The reference chases four dependent pointers from a ray to its first vertex
+// (GPUObjectDataVector -> GPUObjectData -> LLGPUObjectData -> GPUMeshData -> arrays,
+// SURVEY.md 2.2).  Here rt_scene_commit flattens every instance into world space once, with
+// the reference's own arithmetic (matVecMul, GPURaytracer.cu:728-743), so that the render
+// kernel reads fixed-size records addressed by one index.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rt {
+
+constexpr uint32_t kNoHit = 0xFFFFFFFFu;
+constexpr int kLeafMax = 4;        // triangles per BVH leaf
+constexpr int kStackDepth = 64;    // >= 30 Morton bits + 24 index bits + margin
+
+// 48 B: one world-space triangle, three 16-byte loads.  Two arrays of these exist: `triRef`
+// in reference order (object, mesh, triangle: index = gid) and `triLeaf` in BVH leaf order.
+struct TriIsect {
+    float v0x, v0y, v0z; uint32_t gid;   // rank in reference iteration order = tie-break key
+    float v1x, v1y, v1z; uint32_t obj;   // object index (array order of rt_scene_commit)
+    float v2x, v2y, v2z; uint32_t pad;
+};
+static_assert(sizeof(TriIsect) == 48, "TriIsect layout");
+
+// 80 B, reference order: everything the winner needs besides its positions
+struct TriShade {
+    float n0[3], n1[3], n2[3];   // inverse-transpose transformed vertex normals (un-normalised)
+    float uv0[2], uv1[2], uv2[2];
+    uint32_t obj, mesh, tri;     // hit ids: object, mesh-in-object, triangle-in-mesh
+    uint32_t matFlags;           // material id | hasNormals << 31
+    uint32_t pad;
+};
+static_assert(sizeof(TriShade) == 80, "TriShade layout");
+
+// 96 B per object: what intersectsObjectBoundingBox (GPURaytracer.cu:267-315) reads
+struct ObjCull {
+    float inv[16];
+    float bmin[3];
+    float bmax[3];
+    uint32_t triStart;  // first gid of this object
+    uint32_t triCount;
+};
+static_assert(sizeof(ObjCull) == 96, "ObjCull layout");
+
+struct DevTexture {
+    const uchar4* data;
+    int32_t w, h;
+};
+
+struct DevMaterial { // 64 B
+    float albedo[4];
+    float roughness, metal;
+    float emission[3];
+    float strength;
+    int32_t texNormal, texAlbedo, texRoughness, texMetal;
+    uint32_t pad[2];
+};
+static_assert(sizeof(DevMaterial) == 64, "DevMaterial layout");
+
+// 64 B binary BVH node: both child boxes live in the parent, so one node fetch (four 16-byte
+// loads, one 64-byte segment) decides both children.
+// child >= 0: internal node index; child < 0: leaf, ~child = (first << 3) | (count - 1)
+struct BvhNode {
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
+    int32_t left, right;
+    uint32_t pad[2];
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode layout");
+
+struct SceneView {
+    const TriIsect* triRef;    // [nTris] reference order
+    const TriIsect* triLeaf;   // [nTris] BVH leaf order
+    const TriShade* triShade;  // [nTris] reference order
+    const ObjCull* objects;    // [nObjects]
+    const DevMaterial* materials;
+    const DevTexture* textures;
+    const BvhNode* nodes;
+    uint32_t nTris;
+    uint32_t nObjects;
+    int32_t rootIsValid;       // 0 when the scene holds no triangle
+    float sceneMaxAbs;         // max |coordinate| over all world-space vertices
+};
+
+struct RenderArgs {
+    SceneView scene;
+    // CameraParams (GPURaytracer.hpp:60-69)
+    float camOrigin[4];
+    float camRotation[4];
+    float exposure;
+    int32_t width, height;
+    const float4* rays;        // W*H pre-rotation directions
+    // RendererParams (:78-87)
+    int32_t bounceCount;
+    float maxDistance;
+    float aoIntensity;
+    uint32_t frameCount;
+    uint32_t progressiveFrameCount;
+    int32_t antiAliasing;
+    uint32_t sampleCount;
+    // SkyLightParams (:71-76)
+    float skyDir[4], lightColor[4], skyColor[4];
+    // tile + output
+    int32_t x0, y0, x1, y1;
+    float4* fb;
+    uint4* ids;                // may be null
+    unsigned long long* counters; // [0] rays, [1] slow-path rays, [2] node visits, [3] tri tests
+    int32_t tilesX, tilesY;
+};
+
+} // namespace rt

@@ -1,0 +1,484 @@
+// rt_render.hip -- the per-pixel render kernel for gfx950 (wave64).
+//
+// Replaces raytraceKernel and everything it inlines (processor/GPU/GPURaytracer.cu:78-885) plus
+// the GPUMaterial getters (Material.cu:268-323).  Result semantics follow the reference line by
+// line (each device function cites it); the execution shape does not:
+//  * a wavefront owns a compact pixel tile (8x8, 8x4 or 4x4 pixels) times 1, 2 or 4 sample lanes,
+//    chosen from sampleCount so that no lane is idle at 1 spp (the reference always launches
+//    4 z-lanes per pixel and parks three of them at 1 spp);
+//  * the reference's shared-memory reduction over the z lanes becomes a wave shuffle in the same
+//    summation order;
+//  * workgroup ids are remapped so that the workgroups sharing an XCD (and its 4 MiB L2) render
+//    one contiguous band of the tile;
+//  * geometry comes from the flattened world-space records of rt_device.h, through a BVH;
+//  * gfx950 has no texture unit: bilinear filtering is done in software on RGBA8 texels
+//    (value = byte/255.0f at fetch, the reference's own conversion, Material.cu:203).
+#include "rt_trace.h"
+
+namespace rt {
+
+constexpr float kPi = 3.141592f; // processor/Raytracer.hpp:16
+
+struct V4 { float x, y, z, w; };
+__device__ __forceinline__ V4 mk4(float x, float y, float z, float w) { V4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+__device__ __forceinline__ float dot3(const V4& a, const V4& b) { return a.x * b.x + a.y * b.y + a.z * b.z; } // :781
+__device__ __forceinline__ V4 normalize4(const V4& v) // :807-811, rsqrtf := 1/sqrtf
+{
+    const float inv = rtd::rsqrt_f(v.x * v.x + v.y * v.y + v.z * v.z);
+    return mk4(v.x * inv, v.y * inv, v.z * inv, v.w);
+}
+__device__ __forceinline__ V4 cross4(const V4& a, const V4& b) // :771-779
+{
+    return mk4(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x, 0.0f);
+}
+__device__ __forceinline__ V4 lerp4(const V4& a, const V4& b, float t) // :796-805
+{
+    return mk4(a.x + (b.x - a.x) * t, a.y + (b.y - a.y) * t, a.z + (b.z - a.z) * t, a.w + (b.w - a.w) * t);
+}
+__device__ __forceinline__ V4 reflect4(const V4& v, const V4& n) // :861-872
+{
+    const float d = dot3(v, n);
+    return normalize4(mk4(v.x - 2.0f * d * n.x, v.y - 2.0f * d * n.y, v.z - 2.0f * d * n.z, 0.0f));
+}
+__device__ __forceinline__ V4 rotate_q(const V4& v, const float* q) // :700-717, q = x,y,z,w
+{
+    const float qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+    const float t2 = qw * qx, t3 = qw * qy, t4 = qw * qz;
+    const float t5 = -qx * qx, t6 = qx * qy, t7 = qx * qz;
+    const float t8 = -qy * qy, t9 = qy * qz, t10 = -qz * qz;
+    return mk4(2.0f * ((t8 + t10) * v.x + (t6 - t4) * v.y + (t3 + t7) * v.z) + v.x,
+               2.0f * ((t4 + t6) * v.x + (t5 + t10) * v.y + (t9 - t2) * v.z) + v.y,
+               2.0f * ((t7 - t3) * v.x + (t2 + t9) * v.y + (t5 + t8) * v.z) + v.z, v.w);
+}
+
+// :819-825
+__device__ __forceinline__ float random_value(uint32_t& seed)
+{
+    seed = seed * 747796405u + 2891336453u;
+    uint32_t r = ((seed >> ((seed >> 28) + 4u)) ^ seed) * 277803737u;
+    r = (r >> 22) ^ r;
+    return (float)((double)r / 4294967295.0);
+}
+// :827-833
+__device__ __forceinline__ float random_normal(uint32_t& seed)
+{
+    const float theta = (2.0f * kPi) * random_value(seed);
+    const float r = random_value(seed);
+    const float rho = __builtin_sqrtf(-2.0f * rtd::log_f(r));
+    return rho * rtd::cos_f(theta);
+}
+// :835-841, :853-859
+__device__ __forceinline__ V4 random_cosine_hemi(uint32_t& seed, const V4& n)
+{
+    const float x = random_normal(seed);
+    const float y = random_normal(seed);
+    const float z = random_normal(seed);
+    const V4 u = normalize4(mk4(x, y, z, 0.0f));
+    return normalize4(mk4(u.x + n.x, u.y + n.y, u.z + n.z, 0.0f));
+}
+
+// ---- software bilinear (pinned tex2D definition) ----
+struct Tap { int i0, i1; float a; };
+__device__ __forceinline__ Tap make_tap(float xB, int n)
+{
+    if (!(xB >= -1.0f)) xB = -1.0f;
+    if (xB > (float)n) xB = (float)n;
+    const float f = __builtin_floorf(xB);
+    float a = xB - f;
+    a = __builtin_floorf(a * 256.0f + 0.5f) * (1.0f / 256.0f);
+    int i = (int)f, i1 = i + 1;
+    i = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+    i1 = i1 < 0 ? 0 : (i1 > n - 1 ? n - 1 : i1);
+    Tap t; t.i0 = i; t.i1 = i1; t.a = a;
+    return t;
+}
+__device__ __forceinline__ V4 bilerp(const V4& t00, const V4& t10, const V4& t01, const V4& t11, float a, float b)
+{
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    return mk4(((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x,
+               ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y,
+               ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z,
+               ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w);
+}
+__device__ __forceinline__ V4 texel8(const DevTexture& t, int x, int y)
+{
+    const uchar4 p = t.data[(size_t)y * (size_t)t.w + (size_t)x];
+    return mk4((float)p.x / 255.0f, (float)p.y / 255.0f, (float)p.z / 255.0f, (float)p.w / 255.0f);
+}
+// Material.cu:224-228: normalized coordinates, linear, clamp
+__device__ __forceinline__ V4 tex2d_norm(const DevTexture& t, float u, float v)
+{
+    const Tap tx = make_tap(u * (float)t.w - 0.5f, t.w);
+    const Tap ty = make_tap(v * (float)t.h - 0.5f, t.h);
+    return bilerp(texel8(t, tx.i0, ty.i0), texel8(t, tx.i1, ty.i0), texel8(t, tx.i0, ty.i1), texel8(t, tx.i1, ty.i1),
+                  tx.a, ty.a);
+}
+__device__ __forceinline__ V4 ray_texel(const float4* __restrict__ tab, int w, int x, int y)
+{
+    const float4 p = tab[(size_t)y * (size_t)w + (size_t)x];
+    return mk4(p.x, p.y, p.z, p.w);
+}
+// Camera.hpp:93-97: unnormalized coordinates, linear, clamp
+__device__ __forceinline__ V4 tex2d_rays(const float4* __restrict__ tab, int w, int h, float x, float y)
+{
+    const Tap tx = make_tap(x - 0.5f, w);
+    const Tap ty = make_tap(y - 0.5f, h);
+    return bilerp(ray_texel(tab, w, tx.i0, ty.i0), ray_texel(tab, w, tx.i1, ty.i0), ray_texel(tab, w, tx.i0, ty.i1),
+                  ray_texel(tab, w, tx.i1, ty.i1), tx.a, ty.a);
+}
+
+// :4-20
+__device__ __forceinline__ V4 sky_light(const V4& dir, const RenderArgs& a)
+{
+    const V4 l = mk4(a.skyDir[0], a.skyDir[1], a.skyDir[2], a.skyDir[3]);
+    const float sun = rtd::pow_f(rtd::fmax_f(0.0f, dot3(dir, l)), 1000.0f) * a.lightColor[3];
+    return mk4(a.skyColor[0] * a.skyColor[3] + a.lightColor[0] * sun, a.skyColor[1] * a.skyColor[3] + a.lightColor[1] * sun,
+               a.skyColor[2] * a.skyColor[3] + a.lightColor[2] * sun, 1.0f);
+}
+
+// :640-686
+__device__ __forceinline__ float distribution_ggx(const V4& n, const V4& h, float roughness)
+{
+    const float a = roughness * roughness;
+    const float a2 = a * a;
+    const float ndh = rtd::fmax_f(0.0f, dot3(n, h));
+    const float ndh2 = ndh * ndh;
+    float denom = (ndh2 * (a2 - 1.0f) + 1.0f);
+    denom = kPi * denom * denom;
+    return a2 / (denom + 0.00001f);
+}
+__device__ __forceinline__ float geometry_schlick(float ndv, float roughness)
+{
+    const float r = roughness + 1.0f;
+    const float k = (r * r) / 8.0f;
+    return ndv / (ndv * (1.0f - k) + k);
+}
+
+struct Surface {
+    V4 albedo, normal;
+    float roughness, metal;
+    V4 emission;
+    V4 position;
+};
+
+// winner attributes (:435-548) + material evaluation (:363-377, Material.cu:268-323)
+__device__ __forceinline__ Surface shade_surface(const SceneView& s, const Hit& h, uint32_t& objOut, uint32_t& meshOut,
+                                                 uint32_t& triOut)
+{
+    const float4* tp = reinterpret_cast<const float4*>(s.triRef + h.gid);
+    const float4 A = tp[0], B = tp[1], C = tp[2];
+    const float4* sp = reinterpret_cast<const float4*>(s.triShade + h.gid);
+    const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
+    // TriShade: n0 = s0.xyz, n1 = (s0.w, s1.x, s1.y), n2 = (s1.z, s1.w, s2.x),
+    //           uv0 = (s2.y, s2.z), uv1 = (s2.w, s3.x), uv2 = (s3.y, s3.z), obj = s3.w, mesh,tri,matFlags = s4.xyz
+    const uint32_t matFlags = __float_as_uint(s4.z);
+    objOut = __float_as_uint(s3.w); meshOut = __float_as_uint(s4.x); triOut = __float_as_uint(s4.y);
+    const bool hasNormals = (matFlags >> 31) != 0;
+    const DevMaterial m = s.materials[matFlags & 0x7FFFFFFFu];
+
+    const V4 e1 = mk4(B.x - A.x, B.y - A.y, B.z - A.z, 0.0f);
+    const V4 e2 = mk4(C.x - A.x, C.y - A.y, C.z - A.z, 0.0f);
+    const float u0 = s2.y, w0 = s2.z, u1 = s2.w, w1 = s3.x, u2 = s3.y, w2 = s3.z;
+    const float du1 = u1 - u0, dv1 = w1 - w0, du2 = u2 - u0, dv2 = w2 - w0;
+    const float f = 1.0f / (du1 * dv2 - du2 * dv1);
+    V4 tangent = mk4(f * (dv2 * e1.x - dv1 * e2.x), f * (dv2 * e1.y - dv1 * e2.y), f * (dv2 * e1.z - dv1 * e2.z), 0.0f);
+    V4 bitangent = mk4(f * (-du2 * e1.x + du1 * e2.x), f * (-du2 * e1.y + du1 * e2.y), f * (-du2 * e1.z + du1 * e2.z), 0.0f);
+    tangent = normalize4(tangent);
+    bitangent = normalize4(bitangent);
+    V4 normal;
+    if (hasNormals) {
+        normal = mk4(s0.x * h.b0 + s0.w * h.b1 + s1.z * h.b2, s0.y * h.b0 + s1.x * h.b1 + s1.w * h.b2,
+                     s0.z * h.b0 + s1.y * h.b1 + s2.x * h.b2, 0.0f);
+        const float corr = dot3(tangent, normal);
+        tangent = normalize4(mk4(tangent.x - corr * normal.x, tangent.y - corr * normal.y, tangent.z - corr * normal.z, 0.0f));
+        bitangent = normalize4(cross4(normal, tangent));
+    } else {
+        normal = normalize4(cross4(e2, e1));
+    }
+
+    Surface o;
+    o.position = mk4(A.x * h.b0 + B.x * h.b1 + C.x * h.b2, A.y * h.b0 + B.y * h.b1 + C.y * h.b2,
+                     A.z * h.b0 + B.z * h.b1 + C.z * h.b2, 1.0f);
+    const float u = u0 * h.b0 + u1 * h.b1 + u2 * h.b2;
+    const float v = w0 * h.b0 + w1 * h.b1 + w2 * h.b2;
+
+    o.albedo = m.texAlbedo < 0 ? mk4(m.albedo[0], m.albedo[1], m.albedo[2], m.albedo[3])
+                               : tex2d_norm(s.textures[m.texAlbedo], u, v);
+    V4 nl;
+    if (m.texNormal < 0) nl = mk4(0.0f, 0.0f, 1.0f, 0.0f);
+    else {
+        const V4 n = tex2d_norm(s.textures[m.texNormal], u, v);
+        nl = mk4(n.x * 2 - 1.0f, n.y * 2 - 1.0f, n.z * 2 - 1.0f, 0.0f);
+    }
+    // matVecMul(tbn, nl) with tbn columns (T, B, N, (0,0,0,1)), :522-526, :728-743
+    const V4 nw = mk4(tangent.x * nl.x + bitangent.x * nl.y + normal.x * nl.z + 0.0f * nl.w,
+                      tangent.y * nl.x + bitangent.y * nl.y + normal.y * nl.z + 0.0f * nl.w,
+                      tangent.z * nl.x + bitangent.z * nl.y + normal.z * nl.z + 0.0f * nl.w,
+                      0.0f * nl.x + 0.0f * nl.y + 0.0f * nl.z + 1.0f * nl.w);
+    o.normal = normalize4(nw);
+    o.roughness = m.texRoughness < 0 ? m.roughness : tex2d_norm(s.textures[m.texRoughness], u, v).x;
+    o.metal = m.texMetal < 0 ? m.metal : tex2d_norm(s.textures[m.texMetal], u, v).x;
+    o.emission = mk4(m.emission[0], m.emission[1], m.emission[2], m.strength);
+    return o;
+}
+
+__device__ __forceinline__ uint32_t seg_hash(uint32_t obj, uint32_t mesh, uint32_t tri, uint32_t sample, uint32_t bounce)
+{
+    uint32_t h = obj * 0x9E3779B1u;
+    h ^= (mesh + 0x7F4A7C15u) * 0x85EBCA6Bu;
+    h ^= (tri + 1u) * 0xC2B2AE35u;
+    h ^= sample * 0x27D4EB2Fu + bounce * 0x165667B1u + 1u;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    return h;
+}
+
+struct LaneStats {
+    unsigned long long rays, slow, triBrute;
+    BvhCounters bvh;
+};
+
+template <int MODE>
+__device__ __forceinline__ Hit closest_hit(const SceneView& s, Ray& ray, uint32_t* stack, LaneStats& st)
+{
+    st.rays++;
+    if (MODE == 1) return trace_brute(s, ray, st.triBrute);
+    return trace_bvh(s, ray, stack, st.bvh, st.slow);
+}
+
+// :165-245 for one sample; returns the un-exposed radiance
+template <int MODE>
+__device__ __forceinline__ V4 trace_path(const RenderArgs& a, Ray& ray, uint32_t& seed, uint32_t sample, uint32_t* stack,
+                                         LaneStats& st, uint32_t& checksum, uint32_t* primary)
+{
+    V4 out = mk4(0.0f, 0.0f, 0.0f, 1.0f);
+    V4 beta = mk4(1.0f, 1.0f, 1.0f, 1.0f);
+    for (int i = 0; i < a.bounceCount; i++) {
+        const Hit h = closest_hit<MODE>(a.scene, ray, stack, st);
+        if (h.gid == kNoHit) {
+            checksum += seg_hash(kNoHit, kNoHit, kNoHit, sample, (uint32_t)i);
+            const V4 dir = mk4(ray.dx, ray.dy, ray.dz, 0.0f);
+            const V4 miss = sky_light(dir, a);
+            out.x += miss.x * miss.w * beta.x;
+            out.y += miss.y * miss.w * beta.y;
+            out.z += miss.z * miss.w * beta.z;
+            break;
+        }
+        uint32_t ho, hm, ht;
+        const Surface sf = shade_surface(a.scene, h, ho, hm, ht);
+        checksum += seg_hash(ho, hm, ht, sample, (uint32_t)i);
+        if (i == 0 && sample == 0) { primary[0] = ho; primary[1] = hm; primary[2] = ht; }
+
+        if (i == 0) { // ambient term, AO is the constant (1,1,1) on the device path (Material.cu:41-44)
+            out.x += 1.0f * sf.albedo.x * a.aoIntensity;
+            out.y += 1.0f * sf.albedo.y * a.aoIntensity;
+            out.z += 1.0f * sf.albedo.z * a.aoIntensity;
+        }
+        out.x += sf.emission.x * sf.emission.w * beta.x;
+        out.y += sf.emission.y * sf.emission.w * beta.y;
+        out.z += sf.emission.z * sf.emission.w * beta.z;
+
+        if (i < a.bounceCount - 1) {
+            const float attenuation = 1.0f;
+            const V4 N = sf.normal;
+            const V4 D = mk4(ray.dx, ray.dy, ray.dz, 0.0f);
+            const V4 diffuseDir = random_cosine_hemi(seed, N);
+            const V4 specularDir = reflect4(D, N);
+            const V4 L = normalize4(lerp4(specularDir, diffuseDir, sf.roughness));
+            const V4 V = mk4(-D.x, -D.y, -D.z, D.w);
+            const V4 H = normalize4(mk4(L.x + V.x, L.y + V.y, L.z + V.z, 0.0f));
+            const V4 F0 = lerp4(mk4(0.04f, 0.04f, 0.04f, 1.0f), sf.albedo, sf.metal);
+
+            const float NDF = distribution_ggx(N, H, sf.roughness);
+            const float ndv = rtd::fmax_f(dot3(N, V), 0.0f);
+            const float ndl = rtd::fmax_f(dot3(N, L), 0.0f);
+            const float G = geometry_schlick(ndv, sf.roughness) * geometry_schlick(ndl, sf.roughness);
+            const float cosT = rtd::fmax_f(dot3(H, V), 0.0f);
+            const float pw = rtd::pow_f(1.0f - rtd::fmin_f(cosT, 1.0f), 5.0f);
+            const float Fx = F0.x + (1.0f - F0.x) * pw, Fy = F0.y + (1.0f - F0.y) * pw, Fz = F0.z + (1.0f - F0.z) * pw;
+
+            const float mc = 1.0f - sf.metal;
+            const float kDx = (1.0f - Fx) * mc, kDy = (1.0f - Fy) * mc, kDz = (1.0f - Fz) * mc;
+            const float denominator = 4.0f * ndv * ndl + 0.0001f;
+            const float spx = (NDF * G * Fx) / denominator, spy = (NDF * G * Fy) / denominator, spz = (NDF * G * Fz) / denominator;
+
+            beta.x *= (kDx * sf.albedo.x / kPi + spx) * attenuation * ndl;
+            beta.y *= (kDy * sf.albedo.y / kPi + spy) * attenuation * ndl;
+            beta.z *= (kDz * sf.albedo.z / kPi + spz) * attenuation * ndl;
+
+            const float nudge = 0.0001f;
+            ray.ox = sf.position.x + N.x * nudge;
+            ray.oy = sf.position.y + N.y * nudge;
+            ray.oz = sf.position.z + N.z * nudge;
+            ray.dx = L.x; ray.dy = L.y; ray.dz = L.z;
+        }
+    }
+    return out;
+}
+
+// bijective XCD-aware remap: workgroups b, b+8, b+16, ... share an XCD; give each XCD a
+// contiguous run of tiles (cdna_hip_programming.md section 5, "XCD swizzle must be bijective")
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
+{
+    const uint32_t q = n >> 3, r = n & 7u, xcd = b & 7u, i = b >> 3;
+    const uint32_t base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return base + i;
+}
+
+// LOG2L: log2 of the sample lanes per pixel (0, 1, 2).  MODE: 0 BVH, 1 brute force.
+template <int LOG2L, int MODE>
+__global__ __launch_bounds__(256) void render_kernel(const RenderArgs a)
+{
+    constexpr int L = 1 << LOG2L;
+    constexpr int TW = (L == 4) ? 4 : 8;   // wave tile in pixels
+    constexpr int TH = (L == 1) ? 8 : 4;
+    constexpr int BW = 2 * TW, BH = 2 * TH; // workgroup = 2x2 waves
+
+    const uint32_t nBlocks = (uint32_t)a.tilesX * (uint32_t)a.tilesY;
+    const uint32_t tile = xcd_remap(blockIdx.x, nBlocks);
+    const int ty = (int)(tile / (uint32_t)a.tilesX), tx = (int)(tile % (uint32_t)a.tilesX);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t z = (uint32_t)(lane & (L - 1));
+    const int p = lane >> LOG2L;
+    const int x = a.x0 + tx * BW + (wave & 1) * TW + (p % TW);
+    const int y = a.y0 + ty * BH + (wave >> 1) * TH + (p / TW);
+    const bool inTile = x < a.x1 && y < a.y1;
+    const uint32_t spp = a.sampleCount;
+
+    uint32_t stack[kStackDepth];
+    LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
+    uint32_t checksum = 0;
+    uint32_t primary[3] = { kNoHit, kNoHit, kNoHit };
+
+    float cr = 0.0f, cg = 0.0f, cb = 0.0f; // this lane's partial sum over its samples (:87-105)
+    if (inTile && z < spp) {
+        const uint32_t iters = (spp + 3u) / 4u; // BLOCK_DEPTH = 4 (GPURaytracer.hpp:19)
+        for (uint32_t iter = 0; iter < iters; iter++) {
+            const uint32_t sidx = iter * 4u + z;
+            if (sidx >= spp) break;
+            uint32_t seed = (uint32_t)x + (uint32_t)y * (uint32_t)a.width + sidx * 34673804u + a.frameCount * 719393u;
+
+            // setupRay (:140-163)
+            Ray ray;
+            ray.ox = a.camOrigin[0]; ray.oy = a.camOrigin[1]; ray.oz = a.camOrigin[2];
+            ray.maxDist = a.maxDistance;
+            V4 d;
+            if (a.antiAliasing) {
+                const float xf = (float)x + random_value(seed) - 0.5f;
+                const float yf = (float)y + random_value(seed) - 0.5f;
+                d = tex2d_rays(a.rays, a.width, a.height, xf, yf);
+            } else {
+                d = tex2d_rays(a.rays, a.width, a.height, (float)x, (float)y);
+            }
+            d = normalize4(rotate_q(d, a.camRotation));
+            ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
+
+            const V4 c = trace_path<MODE>(a, ray, seed, sidx, stack, st, checksum, primary);
+            // exposureCorrection (:690-698), per sample
+            cr += 1.0f - rtd::exp_f(-c.x * a.exposure);
+            cg += 1.0f - rtd::exp_f(-c.y * a.exposure);
+            cb += 1.0f - rtd::exp_f(-c.z * a.exposure);
+        }
+    }
+
+    // :107-116 -- lane z == 0 adds the partial sums of z = 0..3 in that order.  Lanes that the
+    // reference never writes (z >= spp) contribute 0.
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+    uint32_t sum = 0;
+    const int base = lane & ~(L - 1);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (i < L) {
+            r += __shfl(cr, base + i);
+            g += __shfl(cg, base + i);
+            b += __shfl(cb, base + i);
+            sum += (uint32_t)__shfl((int)checksum, base + i);
+        } else {
+            r += 0.0f; g += 0.0f; b += 0.0f;
+        }
+    }
+
+    if (inTile && z == 0) {
+        r /= (float)spp; g /= (float)spp; b /= (float)spp;
+        r = rtd::fmin_f(rtd::fmax_f(r, 0.0f), 1.0f); // :125-127
+        g = rtd::fmin_f(rtd::fmax_f(g, 0.0f), 1.0f);
+        b = rtd::fmin_f(rtd::fmax_f(b, 0.0f), 1.0f);
+        const size_t pix = (size_t)y * (size_t)a.width + (size_t)x;
+        if (a.progressiveFrameCount != 0) { // :129-134
+            const float4 prev = a.fb[pix];
+            const float n = (float)a.progressiveFrameCount, n1 = (float)(a.progressiveFrameCount + 1u);
+            r = (r + prev.x * n) / n1;
+            g = (g + prev.y * n) / n1;
+            b = (b + prev.z * n) / n1;
+        }
+        a.fb[pix] = make_float4(r, g, b, 1.0f);
+        if (a.ids) a.ids[pix] = make_uint4(primary[0], primary[1], primary[2], sum);
+    }
+
+    // counters: one atomic per wave and counter
+    unsigned long long v0 = st.rays, v1 = st.slow, v2 = st.bvh.nodes, v3 = st.bvh.tris + st.triBrute;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        v0 += __shfl_xor(v0, off);
+        v1 += __shfl_xor(v1, off);
+        v2 += __shfl_xor(v2, off);
+        v3 += __shfl_xor(v3, off);
+    }
+    if (lane == 0) {
+        atomicAdd(a.counters + 0, v0);
+        if (v1) atomicAdd(a.counters + 1, v1);
+        atomicAdd(a.counters + 2, v2);
+        atomicAdd(a.counters + 3, v3);
+    }
+}
+
+// closest-hit queries for caller-supplied rays (rt_trace_rays)
+template <int MODE>
+__global__ __launch_bounds__(256) void trace_rays_kernel(SceneView s, const float4* __restrict__ rays, int n,
+                                                         uint4* __restrict__ out, unsigned long long* counters)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 r0 = rays[2 * i], r1 = rays[2 * i + 1];
+    Ray ray; ray.ox = r0.x; ray.oy = r0.y; ray.oz = r0.z; ray.maxDist = r0.w; ray.dx = r1.x; ray.dy = r1.y; ray.dz = r1.z;
+    uint32_t stack[kStackDepth];
+    LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
+    const Hit h = closest_hit<MODE>(s, ray, stack, st);
+    uint4 o = make_uint4(kNoHit, kNoHit, kNoHit, kNoHit);
+    if (h.gid != kNoHit) {
+        const TriShade* ts = s.triShade + h.gid;
+        o = make_uint4(ts->obj, ts->mesh, ts->tri, __float_as_uint(h.t));
+    }
+    out[i] = o;
+    if (st.slow) atomicAdd(counters + 1, st.slow);
+}
+
+void launch_render(const RenderArgs& a, int mode, hipStream_t stream)
+{
+    const uint32_t spp = a.sampleCount;
+    const int log2l = spp >= 3 ? 2 : (spp == 2 ? 1 : 0);
+    const int L = 1 << log2l;
+    const int BW = 2 * ((L == 4) ? 4 : 8), BH = 2 * ((L == 1) ? 8 : 4);
+    RenderArgs b = a;
+    b.tilesX = (a.x1 - a.x0 + BW - 1) / BW;
+    b.tilesY = (a.y1 - a.y0 + BH - 1) / BH;
+    const uint32_t grid = (uint32_t)b.tilesX * (uint32_t)b.tilesY;
+    if (grid == 0) return;
+#define RT_LAUNCH(LG, MD) hipLaunchKernelGGL((render_kernel<LG, MD>), dim3(grid), dim3(256), 0, stream, b)
+    if (mode == 1) {
+        if (log2l == 0) RT_LAUNCH(0, 1); else if (log2l == 1) RT_LAUNCH(1, 1); else RT_LAUNCH(2, 1);
+    } else {
+        if (log2l == 0) RT_LAUNCH(0, 0); else if (log2l == 1) RT_LAUNCH(1, 0); else RT_LAUNCH(2, 0);
+    }
+#undef RT_LAUNCH
+}
+
+void launch_trace_rays(const SceneView& s, const float4* rays, int n, uint4* out, unsigned long long* counters, int mode,
+                       hipStream_t stream)
+{
+    if (n <= 0) return;
+    const int grid = (n + 255) / 256;
+    if (mode == 1) hipLaunchKernelGGL((trace_rays_kernel<1>), dim3(grid), dim3(256), 0, stream, s, rays, n, out, counters);
+    else hipLaunchKernelGGL((trace_rays_kernel<0>), dim3(grid), dim3(256), 0, stream, s, rays, n, out, counters);
+}
+
+} // namespace rt
