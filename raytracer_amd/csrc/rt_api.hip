@@ -1,0 +1,675 @@
+// rt_api.hip -- implementation of the C ABI declared in include/rt_api.h.
+// Host-side bookkeeping only; the device work is in rt_commit.hip and rt_render.hip.
+#include "../../include/rt_api.h"
+#include "rt_commit.h"
+#include "rt_detmath.h"
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_createError;
+
+struct MeshRec {
+    bool live = false;
+    float* pos = nullptr; int32_t* idx = nullptr; float* uv = nullptr; float* nrm = nullptr;
+    int32_t nVerts = 0, nTris = 0;
+};
+struct TexRec { bool live = false; uchar4* data = nullptr; int32_t w = 0, h = 0; };
+struct MatRec { bool live = false; rt_material_desc desc; };
+struct ObjRec {
+    bool live = false;
+    std::vector<rt_id> meshes; std::vector<int32_t> matIdx; std::vector<rt_id> mats;
+    float bmin[3], bmax[3];
+};
+struct FbRec {
+    bool live = false, owned = false, idsEnabled = false;
+    float4* data = nullptr; uint4* ids = nullptr; int32_t w = 0, h = 0;
+};
+
+} // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t ownStream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string error;
+    std::vector<MeshRec> meshes;
+    std::vector<TexRec> textures;
+    std::vector<MatRec> materials;
+    std::vector<ObjRec> objects;
+    std::vector<FbRec> fbs;
+
+    rt::BuiltScene built;
+    bool committed = false;
+    rt::ObjCull* dObjects = nullptr; uint32_t nObjects = 0;
+    rt::DevMaterial* dMaterials = nullptr; size_t capMaterials = 0;
+    rt::DevTexture* dTextures = nullptr; size_t capTextures = 0;
+
+    float4* dRays = nullptr; int32_t raysW = 0, raysH = 0;
+    unsigned long long* dCounters = nullptr;   // 4 x u64
+    unsigned long long* hCounters = nullptr;   // pinned
+    hipEvent_t evBegin = nullptr, evEnd = nullptr;
+    hipEvent_t slots[16] = {};
+    bool renderedOnce = false;
+    float commitMs = 0.0f;
+    int optTraversal = 0;
+    int optCounters = 0;
+};
+
+namespace {
+
+int fail(rt_ctx* c, int code, const std::string& msg)
+{
+    if (c) c->error = msg; else g_createError = msg;
+    return code;
+}
+
+#define RT_CHECK(c, call)                                                                       \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail((c), RT_ERR_HIP, std::string(#call) + " failed: " + hipGetErrorString(e_)); \
+    } while (0)
+
+#define RT_BIND(c)                                                                              \
+    do {                                                                                        \
+        if (!(c)) return fail(nullptr, RT_ERR_INVALID, "null context");                         \
+        RT_CHECK((c), hipSetDevice((c)->device));                                               \
+    } while (0)
+
+template <class T> rt_id alloc_slot(std::vector<T>& v)
+{
+    for (size_t i = 0; i < v.size(); i++)
+        if (!v[i].live) return (rt_id)i;
+    v.emplace_back();
+    return (rt_id)(v.size() - 1);
+}
+template <class T> bool valid(const std::vector<T>& v, rt_id id) { return id >= 0 && (size_t)id < v.size() && v[id].live; }
+
+rt::DevMaterial to_dev(const rt_material_desc& d)
+{
+    rt::DevMaterial m;
+    memset(&m, 0, sizeof(m));
+    memcpy(m.albedo, d.albedo, sizeof(m.albedo));
+    m.roughness = d.roughness; m.metal = d.metal;
+    memcpy(m.emission, d.emissionColor, sizeof(m.emission));
+    m.strength = d.emissionStrength;
+    m.texNormal = d.texNormal; m.texAlbedo = d.texAlbedo; m.texRoughness = d.texRoughness; m.texMetal = d.texMetal;
+    return m;
+}
+
+int check_material_desc(rt_ctx* c, const rt_material_desc* d)
+{
+    if (!d) return fail(c, RT_ERR_INVALID, "null material desc");
+    const rt_id t[4] = { d->texNormal, d->texAlbedo, d->texRoughness, d->texMetal };
+    for (int i = 0; i < 4; i++)
+        if (t[i] != -1 && !valid(c->textures, t[i])) return fail(c, RT_ERR_INVALID, "material references an invalid texture handle");
+    return RT_OK;
+}
+
+rt::SceneView scene_view(const rt_ctx* c)
+{
+    rt::SceneView s;
+    s.triRef = c->built.triRef; s.triLeaf = c->built.triLeaf; s.triShade = c->built.triShade;
+    s.objects = c->dObjects; s.materials = c->dMaterials; s.textures = c->dTextures; s.nodes = c->built.nodes;
+    s.nTris = c->built.nTris; s.nObjects = c->nObjects;
+    s.rootIsValid = c->built.nTris > 0 ? 1 : 0;
+    s.sceneMaxAbs = c->built.sceneMaxAbs;
+    return s;
+}
+
+__global__ void detmath_kernel(int op, const float* __restrict__ in, int n, float* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = in[i];
+    float r;
+    switch (op) {
+    case 0: r = rtd::log_f(x); break;
+    case 1: r = rtd::cos_f(x); break;
+    case 2: r = rtd::exp_f(x); break;
+    case 3: r = rtd::pow_f(x, 5.0f); break;
+    case 4: r = rtd::pow_f(x, 1000.0f); break;
+    case 5: r = rtd::rsqrt_f(x); break;
+    default: {
+        uint32_t seed = __float_as_uint(x);
+        seed = seed * 747796405u + 2891336453u;
+        uint32_t v = ((seed >> ((seed >> 28) + 4u)) ^ seed) * 277803737u;
+        v = (v >> 22) ^ v;
+        r = (float)((double)v / 4294967295.0);
+    }
+    }
+    out[i] = r;
+}
+
+} // namespace
+
+namespace rt {
+void launch_detmath(int op, const float* in, int n, float* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(detmath_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, op, in, n, out);
+}
+} // namespace rt
+
+extern "C" {
+
+const char* rt_version(void) { return "raytracer_amd 0.1 (gfx950)"; }
+
+const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_createError.c_str(); }
+
+int rt_ctx_create(int device, rt_ctx** out)
+{
+    if (!out) return fail(nullptr, RT_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= n) return fail(nullptr, RT_ERR_INVALID, "device index out of range");
+    hipDeviceProp_t prop;
+    RT_CHECK(nullptr, hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(nullptr, RT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library holds gfx950 code only");
+    RT_CHECK(nullptr, hipSetDevice(device));
+    rt_ctx* c = new rt_ctx();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->dCounters, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->hCounters, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipEventCreate(&c->evBegin);
+    if (e == hipSuccess) e = hipEventCreate(&c->evEnd);
+    for (int i = 0; i < 16 && e == hipSuccess; i++) e = hipEventCreate(&c->slots[i]);
+    if (e != hipSuccess) {
+        std::string m = std::string("context set-up failed: ") + hipGetErrorString(e);
+        rt_ctx_destroy(c);
+        return fail(nullptr, RT_ERR_HIP, m);
+    }
+    memset(c->hCounters, 0, 4 * sizeof(unsigned long long));
+    c->stream = c->ownStream;
+    *out = c;
+    return RT_OK;
+}
+
+int rt_ctx_destroy(rt_ctx* c)
+{
+    if (!c) return RT_OK;
+    hipSetDevice(c->device);
+    if (c->ownStream) hipStreamSynchronize(c->ownStream);
+    hipDeviceSynchronize();
+    for (auto& m : c->meshes) if (m.live) { hipFree(m.pos); hipFree(m.idx); hipFree(m.uv); hipFree(m.nrm); }
+    for (auto& t : c->textures) if (t.live) hipFree(t.data);
+    for (auto& f : c->fbs) if (f.live) { if (f.owned) hipFree(f.data); hipFree(f.ids); }
+    rt::free_scene(c->built);
+    hipFree(c->dObjects); hipFree(c->dMaterials); hipFree(c->dTextures); hipFree(c->dRays); hipFree(c->dCounters);
+    if (c->hCounters) hipHostFree(c->hCounters);
+    if (c->evBegin) hipEventDestroy(c->evBegin);
+    if (c->evEnd) hipEventDestroy(c->evEnd);
+    for (int i = 0; i < 16; i++) if (c->slots[i]) hipEventDestroy(c->slots[i]);
+    if (c->ownStream) hipStreamDestroy(c->ownStream);
+    delete c;
+    return RT_OK;
+}
+
+int rt_set_stream(rt_ctx* c, void* s)
+{
+    RT_BIND(c);
+    c->stream = s ? (hipStream_t)s : c->ownStream;
+    return RT_OK;
+}
+
+int rt_set_option(rt_ctx* c, int option, int value)
+{
+    RT_BIND(c);
+    switch (option) {
+    case RT_OPT_TRAVERSAL:
+        if (value != 0 && value != 1) return fail(c, RT_ERR_INVALID, "RT_OPT_TRAVERSAL takes 0 (BVH) or 1 (brute force)");
+        c->optTraversal = value; return RT_OK;
+    case RT_OPT_COUNTERS: c->optCounters = value ? 1 : 0; return RT_OK;
+    default: return fail(c, RT_ERR_INVALID, "unknown option");
+    }
+}
+
+int rt_sync(rt_ctx* c)
+{
+    RT_BIND(c);
+    RT_CHECK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_get_stats(rt_ctx* c, rt_stats* out)
+{
+    RT_BIND(c);
+    if (!out) return fail(c, RT_ERR_INVALID, "null stats pointer");
+    memset(out, 0, sizeof(*out));
+    RT_CHECK(c, hipStreamSynchronize(c->stream));
+    if (c->renderedOnce) {
+        RT_CHECK(c, hipMemcpy(c->hCounters, c->dCounters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        out->rays = c->hCounters[0]; out->slow_path = c->hCounters[1];
+        out->node_visits = c->hCounters[2]; out->tri_tests = c->hCounters[3];
+        float ms = 0.0f;
+        RT_CHECK(c, hipEventElapsedTime(&ms, c->evBegin, c->evEnd));
+        out->kernel_ms = ms;
+    }
+    out->triangles = c->built.nTris; out->bvh_nodes = c->built.nNodes; out->commit_ms = c->commitMs;
+    return RT_OK;
+}
+
+/* ---- scene upload ---- */
+
+int rt_mesh_create(rt_ctx* c, const float* pos, int32_t nVerts, const int32_t* idx, int32_t nTris, const float* uv,
+                   const float* nrm, rt_id* out)
+{
+    RT_BIND(c);
+    if (!out) return fail(c, RT_ERR_INVALID, "null out pointer");
+    if (nVerts < 0 || nTris < 0 || (nVerts > 0 && !pos) || (nTris > 0 && !idx))
+        return fail(c, RT_ERR_INVALID, "mesh arrays missing");
+    for (int64_t i = 0; i < (int64_t)nTris * 3; i++)
+        if (idx[i] < 0 || idx[i] >= nVerts) return fail(c, RT_ERR_INVALID, "mesh index out of range");
+    MeshRec m;
+    m.nVerts = nVerts; m.nTris = nTris;
+    auto up = [&](void** d, const void* h, size_t bytes) -> hipError_t {
+        if (!h || bytes == 0) return hipSuccess;
+        hipError_t e = hipMalloc(d, bytes);
+        if (e != hipSuccess) return e;
+        return hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice);
+    };
+    hipError_t e = up((void**)&m.pos, pos, sizeof(float) * 3 * (size_t)nVerts);
+    if (e == hipSuccess) e = up((void**)&m.idx, idx, sizeof(int32_t) * 3 * (size_t)nTris);
+    if (e == hipSuccess) e = up((void**)&m.uv, uv, sizeof(float) * 2 * (size_t)nVerts);
+    if (e == hipSuccess) e = up((void**)&m.nrm, nrm, sizeof(float) * 3 * (size_t)nVerts);
+    if (e != hipSuccess) {
+        hipFree(m.pos); hipFree(m.idx); hipFree(m.uv); hipFree(m.nrm);
+        return fail(c, RT_ERR_HIP, std::string("mesh upload failed: ") + hipGetErrorString(e));
+    }
+    m.live = true;
+    const rt_id id = alloc_slot(c->meshes);
+    c->meshes[id] = m;
+    *out = id;
+    return RT_OK;
+}
+
+int rt_mesh_destroy(rt_ctx* c, rt_id id)
+{
+    RT_BIND(c);
+    if (!valid(c->meshes, id)) return fail(c, RT_ERR_INVALID, "invalid mesh handle");
+    RT_CHECK(c, hipStreamSynchronize(c->stream));
+    MeshRec& m = c->meshes[id];
+    hipFree(m.pos); hipFree(m.idx); hipFree(m.uv); hipFree(m.nrm);
+    m = MeshRec();
+    return RT_OK;
+}
+
+int rt_texture_create(rt_ctx* c, const uint8_t* rgba8, int32_t w, int32_t h, rt_id* out)
+{
+    RT_BIND(c);
+    if (!out || !rgba8 || w <= 0 || h <= 0) return fail(c, RT_ERR_INVALID, "texture needs rgba8 data and positive extents");
+    TexRec t; t.w = w; t.h = h;
+    RT_CHECK(c, hipMalloc((void**)&t.data, (size_t)w * (size_t)h * 4));
+    hipError_t e = hipMemcpy(t.data, rgba8, (size_t)w * (size_t)h * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(t.data); return fail(c, RT_ERR_HIP, std::string("texture upload failed: ") + hipGetErrorString(e)); }
+    t.live = true;
+    const rt_id id = alloc_slot(c->textures);
+    c->textures[id] = t;
+    *out = id;
+    return RT_OK;
+}
+
+int rt_texture_destroy(rt_ctx* c, rt_id id)
+{
+    RT_BIND(c);
+    if (!valid(c->textures, id)) return fail(c, RT_ERR_INVALID, "invalid texture handle");
+    RT_CHECK(c, hipStreamSynchronize(c->stream));
+    hipFree(c->textures[id].data);
+    c->textures[id] = TexRec();
+    return RT_OK;
+}
+
+int rt_material_create(rt_ctx* c, const rt_material_desc* d, rt_id* out)
+{
+    RT_BIND(c);
+    if (!out) return fail(c, RT_ERR_INVALID, "null out pointer");
+    int r = check_material_desc(c, d);
+    if (r) return r;
+    const rt_id id = alloc_slot(c->materials);
+    c->materials[id].live = true;
+    c->materials[id].desc = *d;
+    *out = id;
+    return RT_OK;
+}
+
+int rt_material_update(rt_ctx* c, rt_id id, const rt_material_desc* d)
+{
+    RT_BIND(c);
+    if (!valid(c->materials, id)) return fail(c, RT_ERR_INVALID, "invalid material handle");
+    int r = check_material_desc(c, d);
+    if (r) return r;
+    c->materials[id].desc = *d;
+    // hot update of a committed scene (the reference re-sends the GPUMaterial, Material.hpp:155-159)
+    if (c->committed && (size_t)id < c->capMaterials) {
+        const rt::DevMaterial m = to_dev(*d);
+        RT_CHECK(c, hipStreamSynchronize(c->stream));
+        RT_CHECK(c, hipMemcpy(c->dMaterials + id, &m, sizeof(m), hipMemcpyHostToDevice));
+    }
+    return RT_OK;
+}
+
+int rt_material_destroy(rt_ctx* c, rt_id id)
+{
+    RT_BIND(c);
+    if (!valid(c->materials, id)) return fail(c, RT_ERR_INVALID, "invalid material handle");
+    c->materials[id] = MatRec();
+    return RT_OK;
+}
+
+int rt_object_create(rt_ctx* c, const rt_id* meshes, const int32_t* matIdx, int32_t nMeshes, const rt_id* mats,
+                     int32_t nMats, const float bmin[3], const float bmax[3], rt_id* out)
+{
+    RT_BIND(c);
+    if (!out || nMeshes < 0 || nMats < 0 || (nMeshes > 0 && (!meshes || !matIdx)) || (nMats > 0 && !mats) || !bmin || !bmax)
+        return fail(c, RT_ERR_INVALID, "object arrays missing");
+    ObjRec o;
+    for (int i = 0; i < nMats; i++) {
+        if (!valid(c->materials, mats[i])) return fail(c, RT_ERR_INVALID, "object references an invalid material handle");
+        o.mats.push_back(mats[i]);
+    }
+    for (int i = 0; i < nMeshes; i++) {
+        if (!valid(c->meshes, meshes[i])) return fail(c, RT_ERR_INVALID, "object references an invalid mesh handle");
+        if (matIdx[i] < 0 || matIdx[i] >= nMats) return fail(c, RT_ERR_INVALID, "mesh material index outside the object's material list");
+        o.meshes.push_back(meshes[i]);
+        o.matIdx.push_back(matIdx[i]);
+    }
+    memcpy(o.bmin, bmin, sizeof(o.bmin));
+    memcpy(o.bmax, bmax, sizeof(o.bmax));
+    o.live = true;
+    const rt_id id = alloc_slot(c->objects);
+    c->objects[id] = o;
+    *out = id;
+    return RT_OK;
+}
+
+int rt_object_destroy(rt_ctx* c, rt_id id)
+{
+    RT_BIND(c);
+    if (!valid(c->objects, id)) return fail(c, RT_ERR_INVALID, "invalid object handle");
+    c->objects[id] = ObjRec();
+    return RT_OK;
+}
+
+int rt_scene_commit(rt_ctx* c, const rt_id* objects, const float* model16, const float* invModel16, int32_t n)
+{
+    RT_BIND(c);
+    if (n < 0 || (n > 0 && (!objects || !model16 || !invModel16))) return fail(c, RT_ERR_INVALID, "commit arrays missing");
+    RT_CHECK(c, hipStreamSynchronize(c->stream));
+
+    std::vector<rt::Segment> segs;
+    std::vector<rt::ObjXform> xf((size_t)n);
+    std::vector<rt::ObjCull> cull((size_t)n);
+    uint64_t total = 0;
+    for (int i = 0; i < n; i++) {
+        if (!valid(c->objects, objects[i])) return fail(c, RT_ERR_INVALID, "commit references an invalid object handle");
+        const ObjRec& o = c->objects[objects[i]];
+        memcpy(xf[i].model, model16 + 16 * (size_t)i, 64);
+        memcpy(xf[i].inv, invModel16 + 16 * (size_t)i, 64);
+        memcpy(cull[i].inv, invModel16 + 16 * (size_t)i, 64);
+        memcpy(cull[i].bmin, o.bmin, 12);
+        memcpy(cull[i].bmax, o.bmax, 12);
+        cull[i].triStart = (uint32_t)total;
+        for (size_t k = 0; k < o.meshes.size(); k++) {
+            if (!valid(c->meshes, o.meshes[k])) return fail(c, RT_ERR_INVALID, "object references a destroyed mesh");
+            const rt_id mat = o.mats[o.matIdx[k]];
+            if (!valid(c->materials, mat)) return fail(c, RT_ERR_INVALID, "object references a destroyed material");
+            const MeshRec& m = c->meshes[o.meshes[k]];
+            if (m.nTris == 0) continue;
+            rt::Segment s;
+            s.gidStart = (uint32_t)total; s.triCount = (uint32_t)m.nTris;
+            s.obj = (uint32_t)i; s.meshInObj = (uint32_t)k; s.materialId = (uint32_t)mat; s.pad = 0;
+            s.pos = m.pos; s.idx = m.idx; s.uv = m.uv; s.nrm = m.nrm;
+            segs.push_back(s);
+            total += (uint64_t)m.nTris;
+        }
+        cull[i].triCount = (uint32_t)(total - cull[i].triStart);
+    }
+    if (total >= (1ull << 28)) return fail(c, RT_ERR_INVALID, "scene exceeds 2^28 triangles");
+
+    // tables
+    rt::free_scene(c->built);
+    c->committed = false;
+    hipFree(c->dObjects); c->dObjects = nullptr; c->nObjects = 0;
+    hipFree(c->dMaterials); c->dMaterials = nullptr; c->capMaterials = 0;
+    hipFree(c->dTextures); c->dTextures = nullptr; c->capTextures = 0;
+
+    if (n > 0) {
+        RT_CHECK(c, hipMalloc((void**)&c->dObjects, sizeof(rt::ObjCull) * (size_t)n));
+        RT_CHECK(c, hipMemcpy(c->dObjects, cull.data(), sizeof(rt::ObjCull) * (size_t)n, hipMemcpyHostToDevice));
+        c->nObjects = (uint32_t)n;
+    }
+    {
+        std::vector<rt::DevMaterial> mats(c->materials.size() ? c->materials.size() : 1);
+        memset(mats.data(), 0, sizeof(rt::DevMaterial) * mats.size());
+        for (size_t i = 0; i < c->materials.size(); i++)
+            if (c->materials[i].live) mats[i] = to_dev(c->materials[i].desc);
+        RT_CHECK(c, hipMalloc((void**)&c->dMaterials, sizeof(rt::DevMaterial) * mats.size()));
+        RT_CHECK(c, hipMemcpy(c->dMaterials, mats.data(), sizeof(rt::DevMaterial) * mats.size(), hipMemcpyHostToDevice));
+        c->capMaterials = mats.size();
+        std::vector<rt::DevTexture> texs(c->textures.size() ? c->textures.size() : 1);
+        memset(texs.data(), 0, sizeof(rt::DevTexture) * texs.size());
+        for (size_t i = 0; i < c->textures.size(); i++)
+            if (c->textures[i].live) { texs[i].data = c->textures[i].data; texs[i].w = c->textures[i].w; texs[i].h = c->textures[i].h; }
+        RT_CHECK(c, hipMalloc((void**)&c->dTextures, sizeof(rt::DevTexture) * texs.size()));
+        RT_CHECK(c, hipMemcpy(c->dTextures, texs.data(), sizeof(rt::DevTexture) * texs.size(), hipMemcpyHostToDevice));
+        c->capTextures = texs.size();
+    }
+
+    rt::Segment* dSegs = nullptr;
+    rt::ObjXform* dXf = nullptr;
+    if (!segs.empty()) {
+        RT_CHECK(c, hipMalloc((void**)&dSegs, sizeof(rt::Segment) * segs.size()));
+        RT_CHECK(c, hipMalloc((void**)&dXf, sizeof(rt::ObjXform) * (size_t)n));
+        RT_CHECK(c, hipMemcpy(dSegs, segs.data(), sizeof(rt::Segment) * segs.size(), hipMemcpyHostToDevice));
+        RT_CHECK(c, hipMemcpy(dXf, xf.data(), sizeof(rt::ObjXform) * (size_t)n, hipMemcpyHostToDevice));
+    }
+    hipEventRecord(c->slots[14], c->stream);
+    std::string err;
+    const bool ok = rt::build_scene(dSegs, (int)segs.size(), dXf, (uint32_t)total, c->built, c->stream, err);
+    hipEventRecord(c->slots[15], c->stream);
+    hipStreamSynchronize(c->stream);
+    hipFree(dSegs); hipFree(dXf);
+    if (!ok) { rt::free_scene(c->built); return fail(c, RT_ERR_HIP, "scene build failed: " + err); }
+    hipEventElapsedTime(&c->commitMs, c->slots[14], c->slots[15]);
+    c->committed = true;
+    return RT_OK;
+}
+
+int rt_camera_set_rays(rt_ctx* c, const float* rays4, int32_t w, int32_t h)
+{
+    RT_BIND(c);
+    if (!rays4 || w <= 0 || h <= 0) return fail(c, RT_ERR_INVALID, "ray table needs data and positive extents");
+    RT_CHECK(c, hipStreamSynchronize(c->stream));
+    if (c->raysW != w || c->raysH != h || !c->dRays) {
+        hipFree(c->dRays); c->dRays = nullptr;
+        RT_CHECK(c, hipMalloc((void**)&c->dRays, sizeof(float4) * (size_t)w * (size_t)h));
+        c->raysW = w; c->raysH = h;
+    }
+    RT_CHECK(c, hipMemcpy(c->dRays, rays4, sizeof(float4) * (size_t)w * (size_t)h, hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+/* ---- output ---- */
+
+int rt_framebuffer_create(rt_ctx* c, int32_t w, int32_t h, rt_id* out)
+{
+    RT_BIND(c);
+    if (!out || w <= 0 || h <= 0) return fail(c, RT_ERR_INVALID, "framebuffer needs positive extents");
+    FbRec f; f.w = w; f.h = h; f.owned = true;
+    RT_CHECK(c, hipMalloc((void**)&f.data, sizeof(float4) * (size_t)w * (size_t)h));
+    hipError_t e = hipMemset(f.data, 0, sizeof(float4) * (size_t)w * (size_t)h);
+    if (e != hipSuccess) { hipFree(f.data); return fail(c, RT_ERR_HIP, "framebuffer clear failed"); }
+    f.live = true;
+    const rt_id id = alloc_slot(c->fbs);
+    c->fbs[id] = f;
+    *out = id;
+    return RT_OK;
+}
+
+int rt_framebuffer_wrap(rt_ctx* c, void* dptr, int32_t w, int32_t h, rt_id* out)
+{
+    RT_BIND(c);
+    if (!out || !dptr || w <= 0 || h <= 0) return fail(c, RT_ERR_INVALID, "framebuffer wrap needs a device pointer and positive extents");
+    if (((uintptr_t)dptr & 15u) != 0) return fail(c, RT_ERR_INVALID, "framebuffer pointer must be 16-byte aligned");
+    FbRec f; f.w = w; f.h = h; f.owned = false; f.data = (float4*)dptr; f.live = true;
+    const rt_id id = alloc_slot(c->fbs);
+    c->fbs[id] = f;
+    *out = id;
+    return RT_OK;
+}
+
+int rt_framebuffer_destroy(rt_ctx* c, rt_id id)
+{
+    RT_BIND(c);
+    if (!valid(c->fbs, id)) return fail(c, RT_ERR_INVALID, "invalid framebuffer handle");
+    RT_CHECK(c, hipStreamSynchronize(c->stream));
+    FbRec& f = c->fbs[id];
+    if (f.owned) hipFree(f.data);
+    hipFree(f.ids);
+    f = FbRec();
+    return RT_OK;
+}
+
+int rt_framebuffer_read(rt_ctx* c, rt_id id, float* host)
+{
+    RT_BIND(c);
+    if (!valid(c->fbs, id) || !host) return fail(c, RT_ERR_INVALID, "invalid framebuffer handle or null host pointer");
+    const FbRec& f = c->fbs[id];
+    RT_CHECK(c, hipMemcpyAsync(host, f.data, sizeof(float4) * (size_t)f.w * (size_t)f.h, hipMemcpyDeviceToHost, c->stream));
+    RT_CHECK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_framebuffer_write(rt_ctx* c, rt_id id, const float* host)
+{
+    RT_BIND(c);
+    if (!valid(c->fbs, id) || !host) return fail(c, RT_ERR_INVALID, "invalid framebuffer handle or null host pointer");
+    const FbRec& f = c->fbs[id];
+    RT_CHECK(c, hipMemcpyAsync(f.data, host, sizeof(float4) * (size_t)f.w * (size_t)f.h, hipMemcpyHostToDevice, c->stream));
+    RT_CHECK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_framebuffer_enable_ids(rt_ctx* c, rt_id id, int enable)
+{
+    RT_BIND(c);
+    if (!valid(c->fbs, id)) return fail(c, RT_ERR_INVALID, "invalid framebuffer handle");
+    FbRec& f = c->fbs[id];
+    if (enable && !f.ids) {
+        RT_CHECK(c, hipMalloc((void**)&f.ids, sizeof(uint4) * (size_t)f.w * (size_t)f.h));
+        RT_CHECK(c, hipMemset(f.ids, 0xFF, sizeof(uint4) * (size_t)f.w * (size_t)f.h));
+    }
+    f.idsEnabled = enable != 0;
+    return RT_OK;
+}
+
+int rt_framebuffer_read_ids(rt_ctx* c, rt_id id, uint32_t* host)
+{
+    RT_BIND(c);
+    if (!valid(c->fbs, id) || !host) return fail(c, RT_ERR_INVALID, "invalid framebuffer handle or null host pointer");
+    const FbRec& f = c->fbs[id];
+    if (!f.ids) return fail(c, RT_ERR_STATE, "hit-id AOV was never enabled on this framebuffer");
+    RT_CHECK(c, hipMemcpyAsync(host, f.ids, sizeof(uint4) * (size_t)f.w * (size_t)f.h, hipMemcpyDeviceToHost, c->stream));
+    RT_CHECK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_render(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* rnd, const rt_sky_params* sky, rt_rect tile,
+              rt_id fb)
+{
+    RT_BIND(c);
+    if (!cam || !rnd || !sky) return fail(c, RT_ERR_INVALID, "null parameter block");
+    if (!c->committed) return fail(c, RT_ERR_STATE, "rt_render before rt_scene_commit");
+    if (!valid(c->fbs, fb)) return fail(c, RT_ERR_INVALID, "invalid framebuffer handle");
+    const FbRec& f = c->fbs[fb];
+    if (cam->width != f.w || cam->height != f.h) return fail(c, RT_ERR_INVALID, "camera extents differ from the framebuffer's");
+    if (!c->dRays || c->raysW != cam->width || c->raysH != cam->height)
+        return fail(c, RT_ERR_STATE, "camera ray table missing or of different extents (rt_camera_set_rays)");
+    if (tile.x0 < 0 || tile.y0 < 0 || tile.x1 > f.w || tile.y1 > f.h || tile.x0 > tile.x1 || tile.y0 > tile.y1)
+        return fail(c, RT_ERR_INVALID, "tile outside the framebuffer");
+    if (rnd->sampleCount == 0) return fail(c, RT_ERR_INVALID, "sampleCount must be at least 1");
+
+    rt::RenderArgs a;
+    memset(&a, 0, sizeof(a));
+    a.scene = scene_view(c);
+    memcpy(a.camOrigin, cam->origin, 16); memcpy(a.camRotation, cam->rotation, 16);
+    a.exposure = cam->exposure; a.width = cam->width; a.height = cam->height; a.rays = c->dRays;
+    a.bounceCount = rnd->bounceCount; a.maxDistance = rnd->maxDistance; a.aoIntensity = rnd->aoIntensity;
+    a.frameCount = rnd->frameCount; a.progressiveFrameCount = rnd->progressiveFrameCount;
+    a.antiAliasing = rnd->antiAliasingEnabled; a.sampleCount = rnd->sampleCount;
+    memcpy(a.skyDir, sky->direction, 16); memcpy(a.lightColor, sky->lightColor, 16); memcpy(a.skyColor, sky->skyColor, 16);
+    a.x0 = tile.x0; a.y0 = tile.y0; a.x1 = tile.x1; a.y1 = tile.y1;
+    a.fb = f.data; a.ids = f.idsEnabled ? f.ids : nullptr; a.counters = c->dCounters;
+
+    RT_CHECK(c, hipMemsetAsync(c->dCounters, 0, 4 * sizeof(unsigned long long), c->stream));
+    RT_CHECK(c, hipEventRecord(c->evBegin, c->stream));
+    rt::launch_render(a, c->optTraversal, c->stream);
+    RT_CHECK(c, hipGetLastError());
+    RT_CHECK(c, hipEventRecord(c->evEnd, c->stream));
+    c->renderedOnce = true;
+    return RT_OK;
+}
+
+int rt_trace_rays(rt_ctx* c, const float* rays, int32_t n, uint32_t* out)
+{
+    RT_BIND(c);
+    if (!c->committed) return fail(c, RT_ERR_STATE, "rt_trace_rays before rt_scene_commit");
+    if (n < 0 || (n > 0 && (!rays || !out))) return fail(c, RT_ERR_INVALID, "ray arrays missing");
+    if (n == 0) return RT_OK;
+    float4* dr = nullptr; uint4* dout = nullptr;
+    RT_CHECK(c, hipMalloc((void**)&dr, 32 * (size_t)n));
+    hipError_t e = hipMalloc((void**)&dout, 16 * (size_t)n);
+    if (e == hipSuccess) e = hipMemcpyAsync(dr, rays, 32 * (size_t)n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->dCounters, 0, 4 * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) {
+        rt::launch_trace_rays(scene_view(c), dr, n, dout, c->dCounters, c->optTraversal, c->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout, 16 * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(dr); hipFree(dout);
+    if (e != hipSuccess) return fail(c, RT_ERR_HIP, std::string("rt_trace_rays failed: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_event_record(rt_ctx* c, int slot)
+{
+    RT_BIND(c);
+    if (slot < 0 || slot >= 14) return fail(c, RT_ERR_INVALID, "event slot must be 0..13");
+    RT_CHECK(c, hipEventRecord(c->slots[slot], c->stream));
+    return RT_OK;
+}
+
+int rt_event_elapsed_ms(rt_ctx* c, int a, int b, float* ms)
+{
+    RT_BIND(c);
+    if (a < 0 || a >= 14 || b < 0 || b >= 14 || !ms) return fail(c, RT_ERR_INVALID, "event slot must be 0..13");
+    RT_CHECK(c, hipEventSynchronize(c->slots[b]));
+    RT_CHECK(c, hipEventElapsedTime(ms, c->slots[a], c->slots[b]));
+    return RT_OK;
+}
+
+int rt_detmath_eval(rt_ctx* c, int op, const float* in, int32_t n, float* out)
+{
+    RT_BIND(c);
+    if (op < 0 || op > 6 || n < 0 || (n > 0 && (!in || !out))) return fail(c, RT_ERR_INVALID, "bad detmath request");
+    if (n == 0) return RT_OK;
+    float *di = nullptr, *dout = nullptr;
+    RT_CHECK(c, hipMalloc((void**)&di, 4 * (size_t)n));
+    hipError_t e = hipMalloc((void**)&dout, 4 * (size_t)n);
+    if (e == hipSuccess) e = hipMemcpyAsync(di, in, 4 * (size_t)n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) { rt::launch_detmath(op, di, n, dout, c->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout, 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(di); hipFree(dout);
+    if (e != hipSuccess) return fail(c, RT_ERR_HIP, std::string("rt_detmath_eval failed: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+} // extern "C"

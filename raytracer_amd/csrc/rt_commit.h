@@ -1,0 +1,44 @@
+// rt_commit.h -- host-visible interface of the scene flatten + BVH build (rt_commit.hip) and of
+// the kernel launchers (rt_render.hip).
+#pragma once
+#include "rt_device.h"
+#include <string>
+
+namespace rt {
+
+// one (object, mesh) pair of the committed scene; triangles [gidStart, gidStart + triCount)
+struct Segment {
+    uint32_t gidStart, triCount;
+    uint32_t obj, meshInObj;
+    uint32_t materialId, pad;
+    const float* pos;
+    const int32_t* idx;
+    const float* uv;   // may be null
+    const float* nrm;  // may be null
+};
+
+struct ObjXform {
+    float model[16];
+    float inv[16];
+};
+
+struct BuiltScene {
+    TriIsect* triRef = nullptr;
+    TriIsect* triLeaf = nullptr;
+    TriShade* triShade = nullptr;
+    BvhNode* nodes = nullptr;
+    uint32_t nTris = 0;
+    uint32_t nNodes = 0;
+    float sceneMaxAbs = 0.0f;
+};
+
+bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t nTris, BuiltScene& out,
+                 hipStream_t stream, std::string& err);
+void free_scene(BuiltScene& s);
+
+void launch_render(const RenderArgs& a, int mode, hipStream_t stream);
+void launch_trace_rays(const SceneView& s, const float4* rays, int n, uint4* out, unsigned long long* counters, int mode,
+                       hipStream_t stream);
+void launch_detmath(int op, const float* in, int n, float* out, hipStream_t stream);
+
+} // namespace rt

@@ -10,6 +10,8 @@
 // render kernel tests exactly the triangles the reference would.
 #include "rt_device.h"
 #include "rt_commit.h"
+#include <cstring>
+#include <string>
 #include <rocprim/rocprim.hpp>
 #include <float.h>
 
