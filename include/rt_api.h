@@ -80,13 +80,15 @@ typedef struct {
     uint32_t bvh_nodes;    /* nodes of the committed acceleration structure */
     float    commit_ms;    /* device time of the last rt_scene_commit */
     uint64_t slow_path;    /* rays that took the exact in-order fallback in the last rt_render */
-    uint64_t node_visits;  /* BVH node visits of the last rt_render (0 unless RT_OPT_COUNTERS) */
-    uint64_t tri_tests;    /* triangle tests of the last rt_render (0 unless RT_OPT_COUNTERS) */
+    uint64_t node_visits;  /* BVH node visits of the last rt_render */
+    uint64_t tri_tests;    /* triangle tests of the last rt_render */
+    uint64_t hits;         /* closest-hit queries that hit and were shaded */
 } rt_stats;
 
 enum rt_option {
     RT_OPT_TRAVERSAL = 1, /* 0 = BVH (default), 1 = brute force in reference order */
-    RT_OPT_COUNTERS = 2   /* 1 = count node visits / triangle tests (slower) */
+    RT_OPT_COUNTERS = 2,  /* reserved */
+    RT_OPT_ACCUMULATE_STATS = 3 /* 1 = rt_render no longer zeroes the counters; setting it zeroes them once */
 };
 
 /* ---- context ---- */

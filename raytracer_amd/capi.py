@@ -48,7 +48,7 @@ class MaterialDesc(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("kernel_ms", C.c_float), ("triangles", C.c_uint32), ("bvh_nodes", C.c_uint32),
                 ("commit_ms", C.c_float), ("slow_path", C.c_uint64), ("node_visits", C.c_uint64),
-                ("tri_tests", C.c_uint64)]
+                ("tri_tests", C.c_uint64), ("hits", C.c_uint64)]
 
 
 EXPORTS = [
@@ -60,7 +60,7 @@ EXPORTS = [
     "rt_render", "rt_trace_rays", "rt_event_record", "rt_event_elapsed_ms", "rt_detmath_eval", "rt_version",
 ]
 
-OPT_TRAVERSAL, OPT_COUNTERS = 1, 2
+OPT_TRAVERSAL, OPT_COUNTERS, OPT_ACCUMULATE_STATS = 1, 2, 3
 
 
 def lib():

@@ -49,7 +49,7 @@ struct rt_ctx {
     rt::DevTexture* dTextures = nullptr; size_t capTextures = 0;
 
     float4* dRays = nullptr; int32_t raysW = 0, raysH = 0;
-    unsigned long long* dCounters = nullptr;   // 4 x u64
+    unsigned long long* dCounters = nullptr;   // 8 x u64
     unsigned long long* hCounters = nullptr;   // pinned
     hipEvent_t evBegin = nullptr, evEnd = nullptr;
     hipEvent_t slots[16] = {};
@@ -57,6 +57,7 @@ struct rt_ctx {
     float commitMs = 0.0f;
     int optTraversal = 0;
     int optCounters = 0;
+    int optAccumulate = 0;
 };
 
 namespace {
@@ -175,8 +176,8 @@ int rt_ctx_create(int device, rt_ctx** out)
     rt_ctx* c = new rt_ctx();
     c->device = device;
     hipError_t e = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->dCounters, 4 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&c->hCounters, 4 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->dCounters, 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->hCounters, 8 * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipEventCreate(&c->evBegin);
     if (e == hipSuccess) e = hipEventCreate(&c->evEnd);
     for (int i = 0; i < 16 && e == hipSuccess; i++) e = hipEventCreate(&c->slots[i]);
@@ -185,7 +186,7 @@ int rt_ctx_create(int device, rt_ctx** out)
         rt_ctx_destroy(c);
         return fail(nullptr, RT_ERR_HIP, m);
     }
-    memset(c->hCounters, 0, 4 * sizeof(unsigned long long));
+    memset(c->hCounters, 0, 8 * sizeof(unsigned long long));
     c->stream = c->ownStream;
     *out = c;
     return RT_OK;
@@ -226,6 +227,10 @@ int rt_set_option(rt_ctx* c, int option, int value)
         if (value != 0 && value != 1) return fail(c, RT_ERR_INVALID, "RT_OPT_TRAVERSAL takes 0 (BVH) or 1 (brute force)");
         c->optTraversal = value; return RT_OK;
     case RT_OPT_COUNTERS: c->optCounters = value ? 1 : 0; return RT_OK;
+    case RT_OPT_ACCUMULATE_STATS:
+        c->optAccumulate = value ? 1 : 0;
+        RT_CHECK(c, hipMemsetAsync(c->dCounters, 0, 8 * sizeof(unsigned long long), c->stream));
+        return RT_OK;
     default: return fail(c, RT_ERR_INVALID, "unknown option");
     }
 }
@@ -244,9 +249,9 @@ int rt_get_stats(rt_ctx* c, rt_stats* out)
     memset(out, 0, sizeof(*out));
     RT_CHECK(c, hipStreamSynchronize(c->stream));
     if (c->renderedOnce) {
-        RT_CHECK(c, hipMemcpy(c->hCounters, c->dCounters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        RT_CHECK(c, hipMemcpy(c->hCounters, c->dCounters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         out->rays = c->hCounters[0]; out->slow_path = c->hCounters[1];
-        out->node_visits = c->hCounters[2]; out->tri_tests = c->hCounters[3];
+        out->node_visits = c->hCounters[2]; out->tri_tests = c->hCounters[3]; out->hits = c->hCounters[4];
         float ms = 0.0f;
         RT_CHECK(c, hipEventElapsedTime(&ms, c->evBegin, c->evEnd));
         out->kernel_ms = ms;
@@ -607,7 +612,7 @@ int rt_render(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* 
     a.x0 = tile.x0; a.y0 = tile.y0; a.x1 = tile.x1; a.y1 = tile.y1;
     a.fb = f.data; a.ids = f.idsEnabled ? f.ids : nullptr; a.counters = c->dCounters;
 
-    RT_CHECK(c, hipMemsetAsync(c->dCounters, 0, 4 * sizeof(unsigned long long), c->stream));
+    if (!c->optAccumulate) RT_CHECK(c, hipMemsetAsync(c->dCounters, 0, 8 * sizeof(unsigned long long), c->stream));
     RT_CHECK(c, hipEventRecord(c->evBegin, c->stream));
     rt::launch_render(a, c->optTraversal, c->stream);
     RT_CHECK(c, hipGetLastError());
@@ -626,7 +631,7 @@ int rt_trace_rays(rt_ctx* c, const float* rays, int32_t n, uint32_t* out)
     RT_CHECK(c, hipMalloc((void**)&dr, 32 * (size_t)n));
     hipError_t e = hipMalloc((void**)&dout, 16 * (size_t)n);
     if (e == hipSuccess) e = hipMemcpyAsync(dr, rays, 32 * (size_t)n, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(c->dCounters, 0, 4 * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->dCounters, 0, 8 * sizeof(unsigned long long), c->stream);
     if (e == hipSuccess) {
         rt::launch_trace_rays(scene_view(c), dr, n, dout, c->dCounters, c->optTraversal, c->stream);
         e = hipGetLastError();

@@ -106,7 +106,7 @@ struct RenderArgs {
     int32_t x0, y0, x1, y1;
     float4* fb;
     uint4* ids;                // may be null
-    unsigned long long* counters; // [0] rays, [1] slow-path rays, [2] node visits, [3] tri tests
+    unsigned long long* counters; // [0] rays, [1] slow-path rays, [2] node visits, [3] tri tests, [4] shaded hits (8 slots)
     int32_t tilesX, tilesY;
 };
 

@@ -233,7 +233,7 @@ __device__ __forceinline__ uint32_t seg_hash(uint32_t obj, uint32_t mesh, uint32
 }
 
 struct LaneStats {
-    unsigned long long rays, slow, triBrute;
+    unsigned long long rays, slow, triBrute, hits;
     BvhCounters bvh;
 };
 
@@ -264,6 +264,7 @@ __device__ __forceinline__ V4 trace_path(const RenderArgs& a, Ray& ray, uint32_t
             break;
         }
         uint32_t ho, hm, ht;
+        st.hits++;
         const Surface sf = shade_surface(a.scene, h, ho, hm, ht);
         checksum += seg_hash(ho, hm, ht, sample, (uint32_t)i);
         if (i == 0 && sample == 0) { primary[0] = ho; primary[1] = hm; primary[2] = ht; }
@@ -345,7 +346,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a)
     const uint32_t spp = a.sampleCount;
 
     uint32_t stack[kStackDepth];
-    LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
+    LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
     uint32_t checksum = 0;
     uint32_t primary[3] = { kNoHit, kNoHit, kNoHit };
 
@@ -415,19 +416,21 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a)
     }
 
     // counters: one atomic per wave and counter
-    unsigned long long v0 = st.rays, v1 = st.slow, v2 = st.bvh.nodes, v3 = st.bvh.tris + st.triBrute;
+    unsigned long long v0 = st.rays, v1 = st.slow, v2 = st.bvh.nodes, v3 = st.bvh.tris + st.triBrute, v4 = st.hits;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         v0 += __shfl_xor(v0, off);
         v1 += __shfl_xor(v1, off);
         v2 += __shfl_xor(v2, off);
         v3 += __shfl_xor(v3, off);
+        v4 += __shfl_xor(v4, off);
     }
     if (lane == 0) {
         atomicAdd(a.counters + 0, v0);
         if (v1) atomicAdd(a.counters + 1, v1);
         atomicAdd(a.counters + 2, v2);
         atomicAdd(a.counters + 3, v3);
+        atomicAdd(a.counters + 4, v4);
     }
 }
 
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(256) void trace_rays_kernel(SceneView s, const floa
     const float4 r0 = rays[2 * i], r1 = rays[2 * i + 1];
     Ray ray; ray.ox = r0.x; ray.oy = r0.y; ray.oz = r0.z; ray.maxDist = r0.w; ray.dx = r1.x; ray.dy = r1.y; ray.dz = r1.z;
     uint32_t stack[kStackDepth];
-    LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
+    LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
     const Hit h = closest_hit<MODE>(s, ray, stack, st);
     uint4 o = make_uint4(kNoHit, kNoHit, kNoHit, kNoHit);
     if (h.gid != kNoHit) {

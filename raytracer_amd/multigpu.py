@@ -1,0 +1,59 @@
+"""Sharding of the render path over the GPUs of one node.
+
+Pixels and samples are independent (the seed is a pure function of x, y, sample index and
+frameCount, GPURaytracer.cu:94), so the scene is replicated and there is no exchange inside a
+frame.  Two partitionings, both pure host logic over a `render(rect, frame_index)` callback so
+that they can be exercised on CPU with gloo:
+
+ * tiles:   one frame, row bands dealt round-robin to the ranks (sky bands are cheap, so
+            interleaving balances the load); composite = all_gather of each rank's bands.
+            Seeds use global pixel coordinates, so the composite is bit-identical to the
+            single-GPU frame.
+ * frames:  progressive accumulation; frame index f belongs to rank f % world.  Every rank
+            sums its own clamped frames, the sums are combined with one reduce(SUM), and the
+            mean is sum / frames.  (The reference's running mean (c + prev*n)/(n+1),
+            GPURaytracer.cu:129-134, differs from sum/N only by rounding.)
+"""
+from typing import List, Tuple
+
+BAND_ROWS = 16  # multiple of every workgroup tile height (8 or 16 rows)
+
+
+def band_rects(width: int, height: int, rank: int, world: int, band_rows: int = BAND_ROWS) -> List[Tuple[int, int, int, int]]:
+    """Row bands [y0, y1) owned by `rank`: band b belongs to rank b % world."""
+    rects = []
+    nb = (height + band_rows - 1) // band_rows
+    for b in range(rank, nb, world):
+        rects.append((0, b * band_rows, width, min(height, (b + 1) * band_rows)))
+    return rects
+
+
+def frame_indices(first: int, count: int, rank: int, world: int) -> List[int]:
+    """Frame indices in [first, first+count) owned by `rank`."""
+    return [f for f in range(first, first + count) if f % world == rank]
+
+
+def composite_tiles(dist, local_fb, width, height, rank, world, band_rows: int = BAND_ROWS):
+    """all_gather of the full-size framebuffers and selection of each band from its owner.
+    `local_fb` is a torch tensor [H, W, 4]; rows not owned by this rank are ignored.
+    (Equal-sized buffers keep the collective a plain all_gather; the GPU bench gathers only the
+    owned bands.)"""
+    import torch
+
+    if world == 1:
+        return local_fb
+    parts = [torch.empty_like(local_fb) for _ in range(world)]
+    dist.all_gather(parts, local_fb)
+    out = torch.empty_like(local_fb)
+    nb = (height + band_rows - 1) // band_rows
+    for b in range(nb):
+        y0, y1 = b * band_rows, min(height, (b + 1) * band_rows)
+        out[y0:y1] = parts[b % world][y0:y1]
+    return out
+
+
+def reduce_frames(dist, local_sum, world, dst=0):
+    """Combine per-rank sums of clamped frames: one reduce(SUM) to `dst`."""
+    if world > 1:
+        dist.reduce(local_sum, dst=dst, op=dist.ReduceOp.SUM)
+    return local_sum
