@@ -1,0 +1,208 @@
+"""CPU tests of the oracle: the reference-derived known answer, its pinned math, the RNG, the
+watertight triangle test, the slab test, the bilinear definition, and the committed goldens."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle_py as orc
+from raytracer_amd import hostmath, scenes
+from raytracer_amd.scene import Camera, Material, MeshObject, Mesh, RenderSettings, Scene
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_golden.npz"))
+
+
+def srgb8(x):
+    x = np.clip(x, 0, 1)
+    return np.floor(np.where(x <= 0.0031308, 12.92 * x, 1.055 * np.power(x, 1 / 2.4) - 0.055) * 255 + 0.5).astype(int)
+
+
+def test_sky_known_answer_from_reference_screenshots():
+    """The only number the reference pins: every sky pixel of its README screenshots
+    (20240610102036.png, 20240610102209.png) is sRGB8 (104,104,139) = linear
+    (0.139292, 0.139292, 0.259182) for the default sky/exposure."""
+    scene, cam, st = scenes.config1(32, 32, 1, 3)
+    fb, ids, _ = orc.render(scene.flatten(), cam, st)
+    px = fb[0, 0, :3]
+    assert ids[0, 0, 0] == 0xFFFFFFFF
+    np.testing.assert_allclose(px, [0.139292, 0.139292, 0.259182], atol=2e-6)
+    assert list(srgb8(px)) == [104, 104, 139]
+
+
+def test_reference_screenshot_sky_pixel_if_present():
+    p = "/root/reference/20240610102036.png"
+    if not os.path.exists(p):
+        pytest.skip("reference checkout not present")
+    from PIL import Image
+    im = np.asarray(Image.open(p).convert("RGB"))
+    assert tuple(im[5, 5]) == (104, 104, 139)
+
+
+def test_rng_stream_matches_definition():
+    L = orc.lib()
+    seed = C.c_uint32(12345)
+    got = np.array([L.or_random_value(C.byref(seed)) for _ in range(64)], np.float32)
+    s = 12345
+    exp = []
+    for _ in range(64):
+        s = (s * 747796405 + 2891336453) & 0xFFFFFFFF
+        r = (((s >> ((s >> 28) + 4)) ^ s) * 277803737) & 0xFFFFFFFF
+        r = ((r >> 22) ^ r) & 0xFFFFFFFF
+        exp.append(np.float32(r / 4294967295.0))
+    assert np.array_equal(got, np.array(exp, np.float32))
+    assert np.array_equal(got, GOLD["rng_seed12345"])
+
+
+@pytest.mark.parametrize("name,fn,ref,lo,hi", [
+    ("log", "or_logf", np.log, 1e-30, 1.0), ("cos", "or_cosf", np.cos, 0.0, 6.283184),
+    ("exp", "or_expf", np.exp, -90.0, 0.0), ("exp_pos", "or_expf", np.exp, 0.0, 80.0)])
+def test_detmath_is_correctly_rounded(name, fn, ref, lo, hi):
+    L = orc.lib()
+    rng = np.random.default_rng(5)
+    x = (lo + (hi - lo) * rng.random(20000)).astype(np.float32)
+    got = np.array([getattr(L, fn)(float(v)) for v in x], np.float32)
+    exp = ref(x.astype(np.float64)).astype(np.float32)
+    ulp = np.abs(got.view(np.int32).astype(np.int64) - exp.view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1 and (ulp == 0).mean() > 0.9999
+
+
+def test_detmath_pow_and_specials():
+    L = orc.lib()
+    rng = np.random.default_rng(6)
+    x = rng.random(5000).astype(np.float32)
+    for y in (5.0, 1000.0):
+        xs = x if y == 5.0 else (1 - 0.05 * x).astype(np.float32)
+        got = np.array([L.or_powf(float(v), y) for v in xs], np.float32)
+        exp = np.power(xs.astype(np.float64), y).astype(np.float32)
+        ulp = np.abs(got.view(np.int32).astype(np.int64) - exp.view(np.int32).astype(np.int64))
+        assert ulp.max() <= 1
+    assert L.or_logf(0.0) == -np.inf and L.or_logf(1.0) == 0.0 and np.isnan(L.or_logf(-1.0))
+    assert L.or_powf(0.0, 1000.0) == 0.0 and L.or_powf(1.0, 1000.0) == 1.0
+    assert L.or_expf(-200.0) == 0.0 and L.or_expf(100.0) == np.inf and L.or_expf(0.0) == 1.0
+    assert L.or_rsqrtf(4.0) == 0.5
+
+
+def _tri(o, d, v0, v1, v2, maxd=100.0):
+    L = orc.lib()
+    t = C.c_float()
+    b = np.zeros(3, np.float32)
+    a = [np.ascontiguousarray(x, np.float32) for x in (o, d, v0, v1, v2)]
+    hit = L.or_dist_to_triangle(a[0].ctypes.data, a[1].ctypes.data, maxd, a[2].ctypes.data, a[3].ctypes.data,
+                                a[4].ctypes.data, C.byref(t), b.ctypes.data)
+    return hit, t.value, b
+
+
+def test_triangle_known_answers():
+    v0, v1, v2 = (-1, -1, 0), (1, -1, 0), (0, 1, 0)
+    hit, t, b = _tri((0, 0, 5), (0, 0, -1), v0, v1, v2)
+    assert hit and t == 5.0 and abs(b.sum() - 1) < 1e-6
+    assert not _tri((0, 0, 5), (0, 0, 1), v0, v1, v2)[0]           # behind
+    assert not _tri((0, 0, 5), (0, 0, -1), v0, v1, v2, maxd=4.0)[0]  # beyond maxDistance
+    assert not _tri((0, 0, 0.0005), (0, 0, -1), v0, v1, v2)[0]     # t < 0.001
+    assert not _tri((3, 0, 5), (0, 0, -1), v0, v1, v2)[0]          # outside
+    # both windings hit (no back-face culling in the reference)
+    assert _tri((0, 0, 5), (0, 0, -1), v0, v2, v1)[0]
+    # shared edge: watertight -- a ray through the edge x = 0 of two triangles hits at least one
+    a = _tri((0, 0.25, 5), (0, 0, -1), (0, -1, 0), (0, 1, 0), (-1, 0, 0))
+    c = _tri((0, 0.25, 5), (0, 0, -1), (0, 1, 0), (0, -1, 0), (1, 0, 0))
+    assert a[0] or c[0]
+    # ray in the triangle's plane: det == 0 -> miss
+    assert not _tri((-5, 0, 0), (1, 0, 0), v0, v1, v2)[0]
+
+
+def _slab(o, d, inv, bmin, bmax, maxd=100.0):
+    L = orc.lib()
+    a = [np.ascontiguousarray(x, np.float32) for x in (o, d, inv, bmin, bmax)]
+    return L.or_slab(a[0].ctypes.data, a[1].ctypes.data, maxd, a[2].ctypes.data, a[3].ctypes.data, a[4].ctypes.data)
+
+
+def test_slab_quirks():
+    eye = np.eye(4, dtype=np.float32).reshape(16)
+    assert _slab((0, 0, 5), (0, 0, -1), eye, (-.5, -.5, -.5), (.5, .5, .5))
+    assert not _slab((2, 0, 5), (0, 0, -1), eye, (-.5, -.5, -.5), (.5, .5, .5))
+    # strict tmin < tmax: a zero-thickness box is never hit
+    assert not _slab((0, 0, 5), (0, 0, -1), eye, (-.5, -.5, 0), (.5, .5, 0))
+    # narrowed maxDistance culls the object
+    assert not _slab((0, 0, 5), (0, 0, -1), eye, (-.5, -.5, -.5), (.5, .5, .5), maxd=4.0)
+    # origin inside the box
+    assert _slab((0, 0, 0), (0, 1, 0), eye, (-.5, -.5, -.5), (.5, .5, .5))
+    # 0 * inf = NaN is dropped by fmaxf/fminf: axis-parallel ray lying on a slab plane still hits
+    assert _slab((0.5, 0, 5), (0, 0, -1), eye, (-.5, -.5, -.5), (.5, .5, .5))
+
+
+def test_bilinear_definition():
+    L = orc.lib()
+    tex = np.zeros((2, 2, 4), np.uint8)
+    tex[0, 0] = (255, 0, 0, 255); tex[0, 1] = (0, 255, 0, 255); tex[1, 0] = (0, 0, 255, 255); tex[1, 1] = (255, 255, 255, 255)
+    t = orc.OrTexture(tex.ctypes.data, 2, 2)
+    out = np.zeros(4, np.float32)
+
+    def s(u, v):
+        L.or_tex2d(C.byref(t), u, v, out.ctypes.data)
+        return out.copy()
+    np.testing.assert_array_equal(s(0.25, 0.25), [1, 0, 0, 1])      # texel centre
+    np.testing.assert_array_equal(s(0.5, 0.25), [0.5, 0.5, 0, 1])   # halfway, weights exactly 1/2
+    np.testing.assert_array_equal(s(-3.0, 0.25), [1, 0, 0, 1])      # clamp
+    np.testing.assert_array_equal(s(9.0, 0.9), [1, 1, 1, 1])
+    np.testing.assert_array_equal(s(float("nan"), 0.25), [1, 0, 0, 1])
+    # weights are quantised to 8 fractional bits: u*2-0.5 = 0.001 -> alpha rounds to 0
+    np.testing.assert_array_equal(s(0.2505, 0.25), [1, 0, 0, 1])
+    # unnormalised ray table: integer coordinate = 50/50 blend of texels x-1 and x
+    tab = np.arange(2 * 3 * 4, dtype=np.float32).reshape(2, 3, 4)
+    L.or_tex2d_rays(tab.ctypes.data, 3, 2, 1.0, 0.5, out.ctypes.data)
+    np.testing.assert_array_equal(out, 0.5 * tab[0, 0] + 0.5 * tab[0, 1])
+
+
+def test_goldens_still_reproduced():
+    for name, (spp, depth, aa) in {"c1_s1": (1, 4, True), "c1_s5": (5, 3, True), "c1_noaa": (1, 2, False)}.items():
+        scene, cam, st = scenes.config1(64, 64, spp, depth)
+        cam.setPosition((0.6, 0.3, 4.0))
+        st.antiAliasingEnabled = aa
+        st.frameCount = 3
+        fb, ids, n = orc.render(scene.flatten(), cam, st)
+        assert np.array_equal(fb, GOLD[name + "_fb"]) and np.array_equal(ids, GOLD[name + "_ids"])
+        assert n == int(GOLD[name + "_rays"][0])
+    scene, cam, st = scenes.config2(96, 54, 4, 4, 64)
+    fb, ids, n = orc.render(scene.flatten(), cam, st)
+    assert np.array_equal(fb, GOLD["c2_fb"]) and np.array_equal(ids, GOLD["c2_ids"])
+
+
+def test_render_properties():
+    scene, cam, st = scenes.config1(48, 48, 2, 3)
+    cam.setPosition((0.6, 0.3, 4.0))
+    flat = scene.flatten()
+    full, ids, n = orc.render(flat, cam, st)
+    # tiles with global coordinates compose to the full frame, thread count does not matter
+    a, _, n1 = orc.render(flat, cam, st, rect=(0, 0, 48, 20), threads=1)
+    b, _, n2 = orc.render(flat, cam, st, rect=(0, 20, 48, 48), threads=3)
+    comp = a.copy(); comp[20:] = b[20:]
+    assert np.array_equal(comp, full) and n1 + n2 == n
+    # progressive running mean (GPURaytracer.cu:129-134)
+    st.progressiveFrameCount = 3
+    prev = np.full((48, 48, 4), 0.25, np.float32)
+    prog, _, _ = orc.render(flat, cam, st, prev=prev)
+    exp = (full[..., :3] + prev[..., :3] * np.float32(3)) / np.float32(4)
+    assert np.array_equal(prog[..., :3], exp.astype(np.float32))
+    # empty scene: pure sky everywhere
+    st.progressiveFrameCount = 0
+    sky, ids, n = orc.render(Scene().flatten(), cam, st)
+    assert n == 48 * 48 * 2 and (ids[..., 0] == 0xFFFFFFFF).all()
+    assert np.ptp(sky[..., 2]) < 1e-6
+
+
+def test_flat_quad_is_invisible_and_degenerate_uv_gives_nan_normal():
+    quad = Mesh(np.array([-1, -1, 0, 1, -1, 0, 1, 1, 0, -1, 1, 0], np.float32), np.array([0, 1, 2, 0, 2, 3], np.int32),
+                np.array([0, 0, 1, 0, 1, 1, 0, 1], np.float32), None)
+    sc = Scene(); m = Material("m"); o = MeshObject([(quad, 0)], [m]); sc.addToScene("q", o)
+    cam = Camera((0, 0, 5)); cam.setWidth(16); cam.setHeight(16); cam.calcRays()
+    st = RenderSettings(bounceCount=2)
+    _, ids, _ = orc.render(sc.flatten(), cam, st)
+    assert (ids[..., 0] == 0xFFFFFFFF).all()
+    # a thin slab with all-zero UVs: hit, tangent = NaN, radiance stays finite only through the
+    # reference's own NaN flow -- the oracle must not crash and must report the hits
+    slab = scenes.box_mesh((-1, -1, -0.1), (1, 1, 0.1))
+    mesh = Mesh(slab[0].reshape(-1), slab[1], np.zeros(slab[2].size, np.float32), slab[3].reshape(-1))
+    sc = Scene(); sc.addToScene("s", MeshObject([(mesh, 0)], [m]))
+    fb, ids, _ = orc.render(sc.flatten(), cam, st)
+    assert (ids[8, 8, 0] == 0)

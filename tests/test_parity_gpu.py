@@ -48,3 +48,304 @@ def test_config1(ctx, mode, spp, depth):
     img, ids, stats = render_gpu(ctx, flat, cam, st, mode)
     check(ref, rid, nq, img, ids, stats)
     assert np.array_equal(img, ref), "radiance is expected to match bit for bit"
+
+
+import os
+
+from raytracer_amd.scene import Camera, Cube, Material, Mesh, MeshObject, RenderSettings, Scene, Sphere, Texture
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_golden.npz"))
+
+
+def compare_modes(ctx, flat, cam, st, exact=True, modes=(1, 0)):
+    ref, rid, nq = orc.render(flat, cam, st)
+    stats = None
+    for mode in modes:
+        img, ids, stats = render_gpu(ctx, flat, cam, st, mode)
+        check(ref, rid, nq, img, ids, stats)
+        if exact:
+            assert np.array_equal(img, ref, equal_nan=True)
+    return ref, rid, stats
+
+
+@pytest.mark.parametrize("mode", [1, 0], ids=["brute", "bvh"])
+def test_committed_goldens(ctx, mode):
+    for name, (spp, depth, aa) in {"c1_s1": (1, 4, True), "c1_s5": (5, 3, True), "c1_noaa": (1, 2, False)}.items():
+        scene, cam, st = scenes.config1(64, 64, spp, depth)
+        cam.setPosition((0.6, 0.3, 4.0))
+        st.antiAliasingEnabled = aa
+        st.frameCount = 3
+        img, ids, stats = render_gpu(ctx, scene.flatten(), cam, st, mode)
+        assert np.array_equal(ids, GOLD[name + "_ids"]) and np.array_equal(img, GOLD[name + "_fb"])
+        assert stats.rays == int(GOLD[name + "_rays"][0])
+    scene, cam, st = scenes.config2(96, 54, 4, 4, 64)
+    img, ids, stats = render_gpu(ctx, scene.flatten(), cam, st, mode)
+    assert np.array_equal(ids, GOLD["c2_ids"]) and np.array_equal(img, GOLD["c2_fb"])
+
+
+def pbr_scene(seed=3, n_obj=24, tex=64):
+    """Random rotated / non-uniformly scaled instances with all four texture kinds bound."""
+    rng = np.random.default_rng(seed)
+    mats = []
+    for k in range(4):
+        m = Material(f"m{k}", tuple(rng.random(3) * 0.8 + 0.1) + (1.0,), float(rng.random()), float(rng.random()),
+                     tuple(rng.random(3)), float(rng.random() * (k == 3)))
+        if k != 1:
+            m.setAlbedoTexture(Texture(scenes.procedural_texture(tex, seed + k, "albedo")))
+        if k % 2 == 0:
+            m.setNormalTexture(Texture(scenes.procedural_texture(tex, seed + 10 + k, "normal")))
+        if k < 3:
+            m.setRoughnessTexture(Texture(scenes.procedural_texture(tex // 2, seed + 20 + k, "scalar")[..., 0]))
+        if k > 0:
+            m.setMetalTexture(Texture(scenes.procedural_texture(tex, seed + 30 + k, "scalar")[..., :3]))
+        mats.append(m)
+    ell = scenes.merge_meshes([scenes.ellipsoid_mesh(0.5, 0.35, 0.45, 12, 8)])
+    box = scenes.merge_meshes([scenes.box_mesh((-0.4, -0.3, -0.5), (0.4, 0.3, 0.5))])
+    sc = Scene()
+    for i in range(n_obj):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        pos = rng.uniform(-3, 3, 3) * (1, 0.6, 1)
+        scl = rng.uniform(0.5, 1.8, 3)
+        kind = i % 4
+        if kind == 0:
+            o = Sphere(pos, q, scl); o.setMaterial(mats[i % 4])
+        elif kind == 1:
+            o = Cube(); o.setPosition(pos); o.setRotation(q); o.setScale(scl); o.setMaterial(mats[(i // 4) % 4])
+        elif kind == 2:
+            o = MeshObject([(ell, 1), (box, 0)], [mats[i % 4], mats[(i + 1) % 4]], pos, q, scl)
+        else:
+            o = MeshObject([(box, 0)], [mats[(i + 2) % 4]], pos, q, scl)
+        sc.addToScene(f"o{i}", o)
+    q = np.array([-0.1, 0.05, 0.0, 0.99], np.float32); q /= np.linalg.norm(q)
+    cam = Camera((0.3, 1.0, 8.0), q, 50.0, 1.3)
+    return sc, cam
+
+
+@pytest.mark.parametrize("spp,depth,aa", [(1, 4, True), (4, 3, True), (2, 5, False)])
+def test_textured_transformed_instances(ctx, spp, depth, aa):
+    sc, cam = pbr_scene()
+    cam.setWidth(160); cam.setHeight(96); cam.calcRays()
+    st = RenderSettings(bounceCount=depth, sampleCount=spp, antiAliasingEnabled=aa, frameCount=11)
+    compare_modes(ctx, sc.flatten(), cam, st)
+
+
+def random_rays(rng, n, extent=4.0):
+    o = rng.uniform(-extent * 2, extent * 2, (n, 3)).astype(np.float32)
+    tgt = rng.uniform(-extent, extent, (n, 3)).astype(np.float32)
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r = np.zeros((n, 8), np.float32)
+    r[:, :3] = o; r[:, 3] = rng.choice([100.0, 100.0, 7.5, 3.0], n); r[:, 4:7] = d
+    return r
+
+
+def adversarial_rays(flat, rng, n):
+    """Rays aimed exactly at world-space vertices and edge midpoints, and axis-parallel rays."""
+    verts = []
+    for o in flat.objects:
+        m = np.asarray(o["model"], np.float64).reshape(4, 4).T
+        for mid in o["meshIds"]:
+            v = flat.meshes[mid].vertices.reshape(-1, 3).astype(np.float64)
+            verts.append((v @ m[:3, :3].T + m[:3, 3]).astype(np.float32))
+    verts = np.concatenate(verts)
+    a = verts[rng.integers(0, len(verts), n)]
+    b = verts[rng.integers(0, len(verts), n)]
+    tgt = np.where(rng.random((n, 1)) < 0.5, a, (0.5 * (a + b)).astype(np.float32))
+    o = rng.uniform(-9, 9, (n, 3)).astype(np.float32)
+    axis = rng.random(n) < 0.25
+    k = rng.integers(0, 3, n)
+    o[axis] = tgt[axis]
+    o[axis, k[axis]] += rng.choice([-7.0, 7.0], axis.sum()).astype(np.float32)
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r = np.zeros((n, 8), np.float32)
+    r[:, :3] = o; r[:, 3] = 100.0; r[:, 4:7] = d.astype(np.float32)
+    return r
+
+
+def test_trace_rays_random_and_adversarial(ctx):
+    sc, _ = pbr_scene(seed=9, n_obj=40)
+    flat = sc.flatten()
+    rng = np.random.default_rng(1)
+    rays = np.concatenate([random_rays(rng, 60000), adversarial_rays(flat, rng, 60000)])
+    ref = orc.trace_rays(flat, rays)
+    for mode in (1, 0):
+        ctx.set_option(capi.OPT_TRAVERSAL, mode)
+        ctx.upload_scene(flat)
+        got = ctx.trace_rays(rays)
+        bad = np.nonzero((got != ref).any(axis=1))[0]
+        assert bad.size == 0, (mode, bad[:5], got[bad[:5]], ref[bad[:5]])
+    assert (ref[:, 0] != 0xFFFFFFFF).mean() > 0.3
+
+
+def touching_scene():
+    """Objects that touch or coincide: coplanar shared faces, exact duplicates (z-fighting) and a
+    sphere resting on a slab.  Exercises the in-order exact path of the BVH traversal."""
+    sc = Scene()
+    m = Material("a", (0.7, 0.3, 0.3, 1), 0.4, 0.2)
+    n = Material("b", (0.3, 0.7, 0.3, 1), 0.6, 0.0)
+    for i, x in enumerate((-1.0, 0.0, 1.0)):   # three unit cubes sharing faces
+        c = Cube(); c.setPosition((x, 0.0, 0.0)); c.setMaterial(m if i % 2 else n); sc.addToScene(f"c{i}", c)
+    d = Cube(); d.setPosition((0.0, 0.0, 0.0)); d.setMaterial(m); sc.addToScene("dup", d)          # exact duplicate of c1
+    e = Cube(); e.setPosition((0.0, 1.0, 0.0)); e.setMaterial(n); sc.addToScene("top", e)          # stacked, shared face
+    s = Sphere(position=(0.0, 2.0, 0.0)); s.setMaterial(m); sc.addToScene("ball", s)                # rests on `top`
+    s2 = Sphere(position=(0.0, 2.0, 0.0)); s2.setMaterial(n); sc.addToScene("ball2", s2)            # duplicate sphere
+    return sc
+
+
+def test_touching_and_duplicate_objects_take_the_exact_path(ctx):
+    sc = touching_scene()
+    cam = Camera((1.2, 2.0, 6.0), (-0.12, 0.08, 0.0, 0.99), 45.0, 1.0)
+    cam.setWidth(128); cam.setHeight(128); cam.calcRays()
+    st = RenderSettings(bounceCount=4, sampleCount=2)
+    flat = sc.flatten()
+    _, _, stats = compare_modes(ctx, flat, cam, st)
+    assert stats.slow_path > 0
+    rng = np.random.default_rng(4)
+    rays = np.concatenate([random_rays(rng, 40000, 2.0), adversarial_rays(flat, rng, 40000)])
+    ref = orc.trace_rays(flat, rays)
+    ctx.set_option(capi.OPT_TRAVERSAL, 0)
+    ctx.upload_scene(flat)
+    got = ctx.trace_rays(rays)
+    assert np.array_equal(got, ref)
+
+
+def test_edge_cases(ctx):
+    cam = Camera((0, 0, 5)); cam.setWidth(40); cam.setHeight(24); cam.calcRays()
+    st = RenderSettings(bounceCount=3, sampleCount=1)
+    # empty scene
+    compare_modes(ctx, Scene().flatten(), cam, st)
+    # a flat quad is invisible (strict slab test); a single triangle inside generous bounds is not
+    quad = Mesh(np.array([-1, -1, 0, 1, -1, 0, 1, 1, 0, -1, 1, 0], np.float32), np.array([0, 1, 2, 0, 2, 3], np.int32),
+                np.array([0, 0, 1, 0, 1, 1, 0, 1], np.float32), None)
+    m = Material("m")
+    sc = Scene(); sc.addToScene("q", MeshObject([(quad, 0)], [m]))
+    _, rid, _ = compare_modes(ctx, sc.flatten(), cam, st)
+    assert (rid[..., 0] == 0xFFFFFFFF).all()
+    tri = Mesh(np.array([-1, -1, 0, 1, -1, 0, 0, 1, 0], np.float32), np.array([0, 1, 2], np.int32),
+               np.array([0, 0, 1, 0, 0.5, 1], np.float32), None)
+    o = MeshObject([(tri, 0)], [m])
+    o.compositeMinBounds = np.array([-1, -1, -0.5], np.float32); o.compositeMaxBounds = np.array([1, 1, 0.5], np.float32)
+    sc = Scene(); sc.addToScene("t", o)
+    _, rid, _ = compare_modes(ctx, sc.flatten(), cam, st)
+    assert (rid[..., 0] == 0).any()
+    # degenerate UVs: NaN tangent frame flows into the shading normal exactly as in the reference
+    slab = scenes.box_mesh((-1, -1, -0.1), (1, 1, 0.1))
+    mesh = Mesh(slab[0].reshape(-1), slab[1], np.zeros(slab[2].size, np.float32), slab[3].reshape(-1))
+    sc = Scene(); sc.addToScene("s", MeshObject([(mesh, 0)], [m]))
+    compare_modes(ctx, sc.flatten(), cam, st)
+    # a mesh without a UV array (the reference would fault; defined as all-zero UVs)
+    mesh = Mesh(slab[0].reshape(-1), slab[1], None, slab[3].reshape(-1))
+    sc = Scene(); sc.addToScene("s", MeshObject([(mesh, 0)], [m]))
+    compare_modes(ctx, sc.flatten(), cam, st)
+    # camera inside an object, tiny maxDistance, bounceCount 1 and 0
+    sc, cam2, st2 = scenes.config1(48, 48, 1, 1)
+    cam2.setPosition((0.0, 0.0, 0.2))
+    compare_modes(ctx, sc.flatten(), cam2, st2)
+    st2.bounceCount = 0
+    compare_modes(ctx, sc.flatten(), cam2, st2)
+    st2.bounceCount = 3; st2.maxDistance = 9.6; cam2.setPosition((0.0, 0.0, 10.0))
+    compare_modes(ctx, sc.flatten(), cam2, st2)
+
+
+def test_tiles_and_progressive(ctx):
+    scene, cam, st = scenes.config2(192, 108, 4, 4, 64)
+    flat = scene.flatten()
+    ref, rid, nq = orc.render(flat, cam, st)
+    ctx.set_option(capi.OPT_TRAVERSAL, 0)
+    ctx.upload_scene(flat)
+    ctx.set_camera_rays(cam.preTransformRays)
+    fb = ctx.framebuffer(192, 108, ids=True)
+    total = 0
+    for rect in [(0, 0, 100, 50), (100, 0, 192, 50), (0, 50, 37, 108), (37, 50, 192, 108)]:  # ragged tiles
+        ctx.render(cam, st, fb, rect)
+        total += ctx.stats().rays
+    assert np.array_equal(ctx.read(fb, 192, 108), ref) and np.array_equal(ctx.read_ids(fb, 192, 108), rid) and total == nq
+    # progressive running mean over three frames equals the oracle's
+    acc = ref
+    for k in (1, 2):
+        st.frameCount = k; st.progressiveFrameCount = k
+        acc, _, _ = orc.render(flat, cam, st, prev=acc)
+        ctx.render(cam, st, fb)
+    assert np.array_equal(ctx.read(fb, 192, 108), acc)
+    ctx.framebuffer_destroy(fb)
+
+
+def test_detmath_matches_oracle_bit_for_bit(ctx):
+    L = orc.lib()
+    rng = np.random.default_rng(8)
+    u = rng.random(200000).astype(np.float32)
+    cases = [(0, u, L.or_logf), (0, np.array([0.0, 1.0, 1e-45, np.inf, -1.0], np.float32), L.or_logf),
+             (1, (u * np.float32(6.283184)).astype(np.float32), L.or_cosf),
+             (1, (u * 2000 - 1000).astype(np.float32), L.or_cosf),
+             (2, (-u * 110).astype(np.float32), L.or_expf), (2, (u * 95).astype(np.float32), L.or_expf),
+             (3, u, lambda x: L.or_powf(x, 5.0)), (4, (1 - u * np.float32(0.03)).astype(np.float32), lambda x: L.or_powf(x, 1000.0)),
+             (5, (u * 100).astype(np.float32), L.or_rsqrtf)]
+    for op, x, f in cases:
+        got = ctx.detmath(op, x)
+        exp = np.array([f(float(v)) for v in x], np.float32)
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), op
+    seeds = rng.integers(0, 2**32, 50000, dtype=np.uint64).astype(np.uint32)
+    got = ctx.detmath(6, seeds.view(np.float32))
+    import ctypes as C
+    exp = np.array([L.or_random_value(C.byref(C.c_uint32(int(s)))) for s in seeds], np.float32)
+    assert np.array_equal(got, exp)
+
+
+def test_error_behaviour(ctx):
+    c2 = capi.Context(0)
+    try:
+        cam = Camera(); cam.setWidth(8); cam.setHeight(8); cam.calcRays()
+        fb = c2.framebuffer(8, 8)
+        with pytest.raises(capi.RtError, match="before rt_scene_commit"):
+            c2.render(cam, RenderSettings(), fb)
+        c2.upload_scene(Scene().flatten())
+        with pytest.raises(capi.RtError, match="ray table"):
+            c2.render(cam, RenderSettings(), fb)
+        c2.set_camera_rays(cam.preTransformRays)
+        with pytest.raises(capi.RtError, match="tile outside"):
+            c2.render(cam, RenderSettings(), fb, (0, 0, 9, 8))
+        with pytest.raises(capi.RtError, match="invalid framebuffer"):
+            c2.render(cam, RenderSettings(), 77)
+        with pytest.raises(capi.RtError, match="sampleCount"):
+            c2.render(cam, RenderSettings(sampleCount=0), fb)
+        c2.render(cam, RenderSettings(), fb)   # still usable after errors
+        assert c2.read(fb, 8, 8)[0, 0, 3] == 1.0
+    finally:
+        c2.close()
+
+
+def test_full_size_properties(ctx):
+    """BASELINE.json configs[1] at full size (1920x1080, 16 spp, depth 4): too large for the CPU
+    oracle, so checked through size-independent properties: determinism, tile composite ==
+    full frame, brute force == BVH on a band, and the oracle on a centred crop."""
+    scene, cam, st = scenes.config2()
+    flat = scene.flatten()
+    W, H = cam.width, cam.height
+    ctx.set_option(capi.OPT_TRAVERSAL, 0)
+    ctx.upload_scene(flat)
+    ctx.set_camera_rays(cam.preTransformRays)
+    fb = ctx.framebuffer(W, H, ids=True)
+    ctx.render(cam, st, fb)
+    a, ia, rays = ctx.read(fb, W, H), ctx.read_ids(fb, W, H), ctx.stats().rays
+    ctx.render(cam, st, fb)
+    assert np.array_equal(ctx.read(fb, W, H), a) and ctx.stats().rays == rays
+    fb2 = ctx.framebuffer(W, H, ids=True)
+    from raytracer_amd import multigpu
+    for r in range(3):
+        for rect in multigpu.band_rects(W, H, r, 3):
+            ctx.render(cam, st, fb2, rect)
+    assert np.array_equal(ctx.read(fb2, W, H), a) and np.array_equal(ctx.read_ids(fb2, W, H), ia)
+    # brute force on a band through the middle
+    ctx.set_option(capi.OPT_TRAVERSAL, 1)
+    ctx.upload_scene(flat)
+    band = (0, 500, W, 532)
+    ctx.render(cam, st, fb2, band)
+    b, ib = ctx.read(fb2, W, H), ctx.read_ids(fb2, W, H)
+    assert np.array_equal(b[500:532], a[500:532]) and np.array_equal(ib[500:532], ia[500:532])
+    # oracle on a 64x64 crop
+    x0, y0 = W // 2 - 32, H // 2 - 32
+    ref, rid, _ = orc.render(flat, cam, st, rect=(x0, y0, x0 + 64, y0 + 64))
+    assert np.array_equal(ref[y0:y0 + 64, x0:x0 + 64], a[y0:y0 + 64, x0:x0 + 64])
+    assert np.array_equal(rid[y0:y0 + 64, x0:x0 + 64], ia[y0:y0 + 64, x0:x0 + 64])
+    ctx.framebuffer_destroy(fb); ctx.framebuffer_destroy(fb2)
