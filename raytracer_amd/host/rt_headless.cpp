@@ -1,0 +1,75 @@
+// rt_headless.cpp -- example and test driver for the C++ host mirror (rt_host.hpp).
+//   rt_headless math                          CPU only: prints the bits of the GLM restatements
+//   rt_headless render OUT.png OUT.f32 W H SPP DEPTH   builds BASELINE config 1 through the class API
+//                                             (Scene/Cube/Sphere/Material/Camera/GPURaytracer), renders it on
+//                                             GPU 0, writes a PNG and the raw float4 framebuffer
+#include "rt_host.hpp"
+
+#include <cstdlib>
+
+using namespace rth;
+
+static void dump(const char* name, const float* f, size_t n)
+{
+    printf("%s", name);
+    for (size_t i = 0; i < n; i++) { uint32_t u; memcpy(&u, &f[i], 4); printf(" %08x", u); }
+    printf("\n");
+}
+
+int main(int argc, char** argv)
+{
+    if (argc >= 2 && std::string(argv[1]) == "math") {
+        const vec3 pos{ 1.5f, -2.0f, 0.25f }, scl{ 2.0f, 0.5f, 1.25f };
+        const quat q{ 0.0f, 0.38268343f, 0.0f, 0.92387953f };
+        mat4 m = identity(); m = translate(m, pos); m = mul(m, mat4_cast(q)); m = scale(m, scl);
+        const mat4 inv = inverse(m);
+        dump("model", &m.c[0][0], 16);
+        dump("inverse", &inv.c[0][0], 16);
+        std::vector<float> rays;
+        Camera::computeRays(7, 5, 45.0f, rays);
+        dump("rays", rays.data(), rays.size());
+        return 0;
+    }
+    if (argc >= 8 && std::string(argv[1]) == "render") {
+        try {
+            const int W = atoi(argv[4]), H = atoi(argv[5]), spp = atoi(argv[6]), depth = atoi(argv[7]);
+            Device dev(0);
+            // RenderWindow's defaults (RenderWindow.cpp:152,167-168): Default material, camera at (0,0,10), FOV 45
+            auto def = std::make_shared<Material>(dev, "Default", vec4{ 0.5f, 0.5f, 0.5f, 1.0f }, 0.5f, 0.0f);
+            def->sendToGPU();
+            Scene scene(dev);
+            auto cube = std::make_shared<Cube>(dev);
+            cube->setMaterial(def);
+            auto sphere = std::make_shared<Sphere>(dev, vec3{ 1.5f, 0.0f, 0.0f });
+            sphere->setMaterial(def);
+            if (!cube->getLoadSuccess() || !sphere->getLoadSuccess()) return 3;
+            cube->sendToGPU(); sphere->sendToGPU();
+            scene.addToScene("cube", cube);
+            scene.addToScene("sphere", sphere);
+            if (scene.addToScene("cube", sphere)) return 4; // duplicate names are refused (Scene.hpp:45-53)
+            Camera cam(dev, vec3{ 0.6f, 0.3f, 4.0f }, quat{}, 45.0f, 1.0f);
+            cam.setWidth(W); cam.setHeight(H);
+            GPURaytracer rt(dev);
+            rt.setBounceCount(depth); rt.setSampleCount(spp); rt.setFrameCount(3);
+            rt.setSkyLight(0.0f, 0.0f, vec4{ 1, 1, 1, 100 }, vec4{ 0.5f, 0.5f, 1.0f, 0.3f });
+            FrameBuffer fb(dev, W, H);
+            rt.raytrace(scene, cam, fb);
+            if (!fb.savePNG(argv[2])) return 5;
+            const std::vector<float> px = fb.read();
+            FILE* f = fopen(argv[3], "wb");
+            if (!f || fwrite(px.data(), 4, px.size(), f) != px.size()) return 6;
+            fclose(f);
+            // PNG round trip through the host mirror's own decoder + the Texture path
+            std::vector<unsigned char> back; int w2, h2, n2;
+            if (!png::decode(argv[2], back, w2, h2, n2) || w2 != W || h2 != H || n2 != 4) return 7;
+            Texture t(dev, argv[2]);
+            if (!t.getLoadSuccess() || t.getWidth() != W) return 8;
+            Material bad(dev, "x");
+            if (bad.setAlbedoTexture("/nonexistent.png")) return 9; // failed loads report false (Material.cu:113-130)
+            printf("ok %dx%d\n", W, H);
+        } catch (const std::exception& e) { fprintf(stderr, "error: %s\n", e.what()); return 2; }
+        return 0;
+    }
+    fprintf(stderr, "usage: rt_headless math | render OUT.png OUT.f32 W H SPP DEPTH\n");
+    return 1;
+}

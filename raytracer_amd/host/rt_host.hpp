@@ -1,0 +1,564 @@
+// rt_host.hpp -- C++ host mirror of the reference's scene-description and renderer API, on top
+// of the C ABI (include/rt_api.h).  Same class and method names, argument meaning and bool error
+// conventions as the reference (src/Material.hpp, Mesh.hpp, DisplayObject.hpp/.cpp, Cube.hpp,
+// Sphere.hpp, Scene.hpp/.cpp, Camera.hpp, processor/Raytracer.hpp, processor/GPU/GPURaytracer.hpp),
+// minus the ImGui editors, the process-wide registries and the GL interop.  Header-only; link
+// with librt_amd.so and zlib.  Build with -ffp-contract=off: the GLM restatements below must
+// produce the same bits as raytracer_amd/hostmath.py (tests/test_host_cpp.py checks it).
+#pragma once
+#include "../../include/rt_api.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+namespace rth {
+
+struct vec3 { float x = 0, y = 0, z = 0; };
+struct vec4 { float x = 0, y = 0, z = 0, w = 0; };
+struct quat { float x = 0, y = 0, z = 0, w = 0; };  // glm::quat() value-initialises to zero
+struct mat4 { float c[4][4]; };                      // c[col][row], GLM convention
+
+inline vec4 col(const mat4& m, int i) { return { m.c[i][0], m.c[i][1], m.c[i][2], m.c[i][3] }; }
+inline void setcol(mat4& m, int i, vec4 v) { m.c[i][0] = v.x; m.c[i][1] = v.y; m.c[i][2] = v.z; m.c[i][3] = v.w; }
+inline vec4 operator*(vec4 a, float s) { return { a.x * s, a.y * s, a.z * s, a.w * s }; }
+inline vec4 operator*(vec4 a, vec4 b) { return { a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w }; }
+inline vec4 operator+(vec4 a, vec4 b) { return { a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w }; }
+inline vec4 operator-(vec4 a, vec4 b) { return { a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w }; }
+
+inline mat4 identity() { mat4 m; for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) m.c[i][j] = i == j ? 1.0f : 0.0f; return m; }
+// glm ext/matrix_transform.inl:10-15
+inline mat4 translate(const mat4& m, vec3 v) { mat4 r = m; setcol(r, 3, col(m, 0) * v.x + col(m, 1) * v.y + col(m, 2) * v.z + col(m, 3)); return r; }
+// glm gtc/quaternion.inl:41-72
+inline mat4 mat4_cast(quat q)
+{
+    mat4 r = identity();
+    const float qxx = q.x * q.x, qyy = q.y * q.y, qzz = q.z * q.z, qxz = q.x * q.z, qxy = q.x * q.y, qyz = q.y * q.z;
+    const float qwx = q.w * q.x, qwy = q.w * q.y, qwz = q.w * q.z;
+    r.c[0][0] = 1.0f - 2.0f * (qyy + qzz); r.c[0][1] = 2.0f * (qxy + qwz); r.c[0][2] = 2.0f * (qxz - qwy);
+    r.c[1][0] = 2.0f * (qxy - qwz); r.c[1][1] = 1.0f - 2.0f * (qxx + qzz); r.c[1][2] = 2.0f * (qyz + qwx);
+    r.c[2][0] = 2.0f * (qxz + qwy); r.c[2][1] = 2.0f * (qyz - qwx); r.c[2][2] = 1.0f - 2.0f * (qxx + qyy);
+    return r;
+}
+// glm detail/type_mat4x4.inl:630-648
+inline mat4 mul(const mat4& a, const mat4& b)
+{
+    mat4 r;
+    for (int c = 0; c < 4; c++) setcol(r, c, col(a, 0) * b.c[c][0] + col(a, 1) * b.c[c][1] + col(a, 2) * b.c[c][2] + col(a, 3) * b.c[c][3]);
+    return r;
+}
+// glm ext/matrix_transform.inl:78-86
+inline mat4 scale(const mat4& m, vec3 v) { mat4 r; setcol(r, 0, col(m, 0) * v.x); setcol(r, 1, col(m, 1) * v.y); setcol(r, 2, col(m, 2) * v.z); setcol(r, 3, col(m, 3)); return r; }
+// glm detail/func_matrix.inl:294-352
+inline mat4 inverse(const mat4& mm)
+{
+    const float(*m)[4] = mm.c;
+    const float c00 = m[2][2] * m[3][3] - m[3][2] * m[2][3], c02 = m[1][2] * m[3][3] - m[3][2] * m[1][3], c03 = m[1][2] * m[2][3] - m[2][2] * m[1][3];
+    const float c04 = m[2][1] * m[3][3] - m[3][1] * m[2][3], c06 = m[1][1] * m[3][3] - m[3][1] * m[1][3], c07 = m[1][1] * m[2][3] - m[2][1] * m[1][3];
+    const float c08 = m[2][1] * m[3][2] - m[3][1] * m[2][2], c10 = m[1][1] * m[3][2] - m[3][1] * m[1][2], c11 = m[1][1] * m[2][2] - m[2][1] * m[1][2];
+    const float c12 = m[2][0] * m[3][3] - m[3][0] * m[2][3], c14 = m[1][0] * m[3][3] - m[3][0] * m[1][3], c15 = m[1][0] * m[2][3] - m[2][0] * m[1][3];
+    const float c16 = m[2][0] * m[3][2] - m[3][0] * m[2][2], c18 = m[1][0] * m[3][2] - m[3][0] * m[1][2], c19 = m[1][0] * m[2][2] - m[2][0] * m[1][2];
+    const float c20 = m[2][0] * m[3][1] - m[3][0] * m[2][1], c22 = m[1][0] * m[3][1] - m[3][0] * m[1][1], c23 = m[1][0] * m[2][1] - m[2][0] * m[1][1];
+    const vec4 f0{ c00, c00, c02, c03 }, f1{ c04, c04, c06, c07 }, f2{ c08, c08, c10, c11 };
+    const vec4 f3{ c12, c12, c14, c15 }, f4{ c16, c16, c18, c19 }, f5{ c20, c20, c22, c23 };
+    const vec4 v0{ m[1][0], m[0][0], m[0][0], m[0][0] }, v1{ m[1][1], m[0][1], m[0][1], m[0][1] };
+    const vec4 v2{ m[1][2], m[0][2], m[0][2], m[0][2] }, v3{ m[1][3], m[0][3], m[0][3], m[0][3] };
+    const vec4 i0 = v1 * f0 - v2 * f1 + v3 * f2, i1 = v0 * f0 - v2 * f3 + v3 * f4;
+    const vec4 i2 = v0 * f1 - v1 * f3 + v3 * f5, i3 = v0 * f2 - v1 * f4 + v2 * f5;
+    const vec4 sa{ 1, -1, 1, -1 }, sb{ -1, 1, -1, 1 };
+    mat4 inv; setcol(inv, 0, i0 * sa); setcol(inv, 1, i1 * sb); setcol(inv, 2, i2 * sa); setcol(inv, 3, i3 * sb);
+    const vec4 row0{ inv.c[0][0], inv.c[1][0], inv.c[2][0], inv.c[3][0] };
+    const vec4 d0 = col(mm, 0) * row0;
+    const float dot1 = (d0.x + d0.y) + (d0.z + d0.w);
+    const float ood = 1.0f / dot1;
+    mat4 r; for (int c = 0; c < 4; c++) setcol(r, c, col(inv, c) * ood);
+    return r;
+}
+
+// ---------------------------------------------------------------- context
+class Device {
+public:
+    explicit Device(int index = 0) { if (rt_ctx_create(index, &ctx_) != RT_OK) throw std::runtime_error(std::string("rt_ctx_create: ") + rt_last_error(nullptr)); }
+    ~Device() { rt_ctx_destroy(ctx_); }
+    Device(const Device&) = delete;
+    rt_ctx* ctx() const { return ctx_; }
+    void check(int rc) const { if (rc != RT_OK) throw std::runtime_error(std::string("librt_amd: ") + rt_last_error(ctx_)); }
+private:
+    rt_ctx* ctx_ = nullptr;
+};
+
+// ---------------------------------------------------------------- PNG (own codec over zlib; the reference vendors lodepng / stb_image)
+namespace png {
+inline void put32(std::vector<unsigned char>& v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); }
+inline void chunk(std::vector<unsigned char>& out, const char* type, const std::vector<unsigned char>& data)
+{
+    put32(out, (uint32_t)data.size());
+    std::vector<unsigned char> body(type, type + 4);
+    body.insert(body.end(), data.begin(), data.end());
+    out.insert(out.end(), body.begin(), body.end());
+    put32(out, (uint32_t)crc32(0L, body.data(), (uInt)body.size()));
+}
+// RGBA8, row 0 = top
+inline bool encode(const std::string& path, const unsigned char* rgba, unsigned w, unsigned h)
+{
+    std::vector<unsigned char> raw;
+    raw.reserve((size_t)h * (w * 4 + 1));
+    for (unsigned y = 0; y < h; y++) { raw.push_back(0); raw.insert(raw.end(), rgba + (size_t)y * w * 4, rgba + (size_t)(y + 1) * w * 4); }
+    uLongf zlen = compressBound((uLong)raw.size());
+    std::vector<unsigned char> z(zlen);
+    if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return false;
+    z.resize(zlen);
+    std::vector<unsigned char> out = { 0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A };
+    std::vector<unsigned char> ihdr; put32(ihdr, w); put32(ihdr, h); ihdr.insert(ihdr.end(), { 8, 6, 0, 0, 0 });
+    chunk(out, "IHDR", ihdr); chunk(out, "IDAT", z); chunk(out, "IEND", {});
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+    fclose(f);
+    return ok;
+}
+inline unsigned char paeth(int a, int b, int c) { const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c); return (unsigned char)((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c)); }
+// Non-interlaced 8/16-bit gray, gray+alpha, RGB, RGBA and 8-bit palette PNGs.  Returns the decoded
+// image with its native channel count; 16-bit samples are reduced with >> 8 as stb_image does.
+inline bool decode(const std::string& path, std::vector<unsigned char>& pix, int& w, int& h, int& nCh)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    std::vector<unsigned char> d;
+    unsigned char buf[65536]; size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) d.insert(d.end(), buf, buf + n);
+    fclose(f);
+    static const unsigned char sig[8] = { 0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A };
+    if (d.size() < 33 || memcmp(d.data(), sig, 8) != 0) return false;
+    auto rd32 = [&](size_t p) { return ((uint32_t)d[p] << 24) | ((uint32_t)d[p + 1] << 16) | ((uint32_t)d[p + 2] << 8) | d[p + 3]; };
+    int depth = 0, ctype = 0, interlace = 0;
+    std::vector<unsigned char> idat, plte;
+    for (size_t p = 8; p + 12 <= d.size();) {
+        const uint32_t len = rd32(p);
+        if (p + 12 + len > d.size()) return false;
+        const std::string t((const char*)&d[p + 4], 4);
+        const unsigned char* body = &d[p + 8];
+        if (t == "IHDR") { w = (int)rd32(p + 8); h = (int)rd32(p + 12); depth = body[8]; ctype = body[9]; interlace = body[12]; }
+        else if (t == "PLTE") plte.assign(body, body + len);
+        else if (t == "IDAT") idat.insert(idat.end(), body, body + len);
+        else if (t == "IEND") break;
+        p += 12 + len;
+    }
+    if (w <= 0 || h <= 0 || interlace != 0 || (depth != 8 && depth != 16) || (ctype == 3 && depth != 8)) return false;
+    const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!ch) return false;
+    const int bpp = ch * depth / 8;
+    const size_t stride = (size_t)w * bpp;
+    std::vector<unsigned char> raw((stride + 1) * (size_t)h);
+    uLongf rlen = (uLongf)raw.size();
+    if (uncompress(raw.data(), &rlen, idat.data(), (uLong)idat.size()) != Z_OK || rlen != raw.size()) return false;
+    std::vector<unsigned char> img(stride * (size_t)h);
+    for (int y = 0; y < h; y++) {
+        const unsigned char ft = raw[(stride + 1) * y];
+        const unsigned char* s = &raw[(stride + 1) * y + 1];
+        unsigned char* o = &img[stride * y];
+        const unsigned char* up = y ? &img[stride * (y - 1)] : nullptr;
+        for (size_t i = 0; i < stride; i++) {
+            const int a = i >= (size_t)bpp ? o[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= (size_t)bpp) ? up[i - bpp] : 0;
+            int v = s[i];
+            switch (ft) { case 1: v += a; break; case 2: v += b; break; case 3: v += (a + b) >> 1; break; case 4: v += paeth(a, b, c); break; default: break; }
+            o[i] = (unsigned char)v;
+        }
+    }
+    nCh = ctype == 3 ? 3 : ch;
+    pix.resize((size_t)w * h * nCh);
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        if (ctype == 3) { const int k = img[i]; for (int c = 0; c < 3; c++) pix[i * 3 + c] = (size_t)(k * 3 + c) < plte.size() ? plte[k * 3 + c] : 0; }
+        else for (int c = 0; c < ch; c++) pix[i * ch + c] = depth == 8 ? img[i * ch + c] : img[(i * ch + c) * 2]; // big-endian high byte = >> 8
+    }
+    return true;
+}
+} // namespace png
+
+// ---------------------------------------------------------------- Texture / Material (Material.hpp:17-117)
+class Texture {
+public:
+    Texture(Device& dev, const char* path) : dev_(dev), path_(path)
+    {
+        std::vector<unsigned char> pix; int n = 0;
+        if (!png::decode(path_, pix, width_, height_, n)) { loadSuccess_ = false; return; } // JPEG: not decoded by this host mirror
+        upload(pix.data(), n);
+    }
+    Texture(Device& dev, const unsigned char* pixels, int w, int h, int nChannels) : dev_(dev), width_(w), height_(h) { upload(pixels, nChannels); }
+    ~Texture() { if (id_ >= 0) rt_texture_destroy(dev_.ctx(), id_); }
+    Texture(const Texture&) = delete;
+    int getWidth() const { return width_; }
+    int getHeight() const { return height_; }
+    bool getLoadSuccess() const { return loadSuccess_; }
+    std::string getPath() const { return path_; }
+    rt_id id() const { return id_; }
+private:
+    void upload(const unsigned char* idata, int n)
+    {
+        // 4-channel expansion with the reference's quirk (Material.cu:184-197): G,B = following bytes
+        const size_t np = (size_t)width_ * height_, total = np * n;
+        std::vector<unsigned char> rgba(np * 4);
+        auto at = [&](size_t k) -> unsigned char { return k < total ? idata[k] : 0; };
+        for (size_t i = 0; i < np; i++) { rgba[i * 4] = at(i * n); rgba[i * 4 + 1] = at(i * n + 1); rgba[i * 4 + 2] = at(i * n + 2); rgba[i * 4 + 3] = n == 4 ? at(i * n + 3) : 255; }
+        loadSuccess_ = rt_texture_create(dev_.ctx(), rgba.data(), width_, height_, &id_) == RT_OK;
+    }
+    Device& dev_;
+    std::string path_;
+    int width_ = 0, height_ = 0;
+    bool loadSuccess_ = false;
+    rt_id id_ = -1;
+};
+
+class Material {
+public:
+    Material(Device& dev, const char* name, vec4 albedo = { 0.9f, 0.9f, 0.9f, 1.0f }, float roughness = 0.5f, float metal = 0.0f,
+             vec3 emissionColor = {}, float emission = 0) : dev_(dev), materialName(name), simpleAlbedo(albedo), simpleRoughness(roughness),
+                                                            simpleMetal(metal), simpleEmissionColor(emissionColor), emissionStrength(emission) {}
+    ~Material() { if (id_ >= 0) rt_material_destroy(dev_.ctx(), id_); }
+    Material(const Material&) = delete;
+    std::string getName() const { return materialName; }
+    bool getSuccess() const { return success; }
+    bool setNormalTexture(const char* p) { return setRef(normalTexture, p); }
+    bool setAlbedoTexture(const char* p) { return setRef(albedoTexture, p); }
+    bool setRoughnessTexture(const char* p) { return setRef(roughnessTexture, p); }
+    bool setMetalTexture(const char* p) { return setRef(metalTexture, p); }
+    bool setAmbientOcclusionTexture(const char* p) { return setRef(ambientOcclusionTexture, p); } // never reaches the device (Material.cu:41-44)
+    bool setEmissionTexture(const char* p) { return setRef(emissionTexture, p); }
+    void setAlbedoTexture(std::shared_ptr<Texture> t) { albedoTexture = std::move(t); }
+    void setNormalTexture(std::shared_ptr<Texture> t) { normalTexture = std::move(t); }
+    void setRoughnessTexture(std::shared_ptr<Texture> t) { roughnessTexture = std::move(t); }
+    void setMetalTexture(std::shared_ptr<Texture> t) { metalTexture = std::move(t); }
+    // Material::sendToGPU (Material.cu:30-49)
+    void sendToGPU()
+    {
+        rt_material_desc d;
+        d.albedo[0] = simpleAlbedo.x; d.albedo[1] = simpleAlbedo.y; d.albedo[2] = simpleAlbedo.z; d.albedo[3] = simpleAlbedo.w;
+        d.roughness = simpleRoughness; d.metal = simpleMetal;
+        d.emissionColor[0] = simpleEmissionColor.x; d.emissionColor[1] = simpleEmissionColor.y; d.emissionColor[2] = simpleEmissionColor.z;
+        d.emissionStrength = emissionStrength;
+        d.texNormal = normalTexture ? normalTexture->id() : -1; d.texAlbedo = albedoTexture ? albedoTexture->id() : -1;
+        d.texRoughness = roughnessTexture ? roughnessTexture->id() : -1; d.texMetal = metalTexture ? metalTexture->id() : -1;
+        dev_.check(id_ < 0 ? rt_material_create(dev_.ctx(), &d, &id_) : rt_material_update(dev_.ctx(), id_, &d));
+    }
+    rt_id id() { if (id_ < 0) sendToGPU(); return id_; }
+private:
+    bool setRef(std::shared_ptr<Texture>& slot, const char* path)
+    {
+        if (!path || !path[0]) { slot.reset(); return true; } // setTextureRef, Material.cu:113-130
+        auto t = std::make_shared<Texture>(dev_, path);
+        if (!t->getLoadSuccess()) return false;
+        slot = std::move(t);
+        return true;
+    }
+    Device& dev_;
+    std::string materialName;
+public:
+    vec4 simpleAlbedo; float simpleRoughness, simpleMetal; vec3 simpleEmissionColor; float emissionStrength;
+private:
+    std::shared_ptr<Texture> normalTexture, albedoTexture, roughnessTexture, metalTexture, ambientOcclusionTexture, emissionTexture;
+    rt_id id_ = -1;
+    bool success = true;
+};
+
+// ---------------------------------------------------------------- Mesh (Mesh.hpp:27-62)
+class Mesh {
+public:
+    Mesh(Device& dev, const std::vector<float>& vertices, const std::vector<int>& indices, const std::vector<float>& uvCoords,
+         const std::vector<float>& normals) : dev_(dev), vertices(vertices), uvCoords(uvCoords), indices(indices), normals(normals)
+    {
+        triangleCount = (int)indices.size() / 3;
+        for (size_t i = 0; i + 2 < vertices.size(); i += 3) // calcBounds, Mesh.hpp:106-122
+            for (int k = 0; k < 3; k++) { minBound[k] = std::min(minBound[k], vertices[i + k]); maxBound[k] = std::max(maxBound[k], vertices[i + k]); }
+        dev_.check(rt_mesh_create(dev_.ctx(), vertices.data(), (int)vertices.size() / 3, indices.data(), triangleCount,
+                                  uvCoords.empty() ? nullptr : uvCoords.data(), normals.empty() ? nullptr : normals.data(), &id_));
+    }
+    ~Mesh() { if (id_ >= 0) rt_mesh_destroy(dev_.ctx(), id_); }
+    Mesh(const Mesh&) = delete;
+    const float* getMinBound() const { return minBound; }
+    const float* getMaxBound() const { return maxBound; }
+    int getTriangleCount() const { return triangleCount; }
+    rt_id id() const { return id_; }
+    const std::vector<float>& getVertices() const { return vertices; }
+    const std::vector<float>& getUVCoords() const { return uvCoords; }
+    const std::vector<int>& getIndices() const { return indices; }
+    const std::vector<float>& getNormals() const { return normals; }
+private:
+    Device& dev_;
+    std::vector<float> vertices, uvCoords; std::vector<int> indices; std::vector<float> normals;
+    float minBound[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, maxBound[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    int triangleCount = 0;
+    rt_id id_ = -1;
+};
+
+// ---------------------------------------------------------------- DisplayObject (DisplayObject.hpp:31-105, .cpp:19-105)
+class DisplayObject {
+public:
+    DisplayObject(Device& dev, vec3 position = {}, quat rotation = {}, vec3 scl = { 1, 1, 1 }) : dev_(dev), Position(position), Rotation(rotation), Scale(scl) {}
+    virtual ~DisplayObject() { if (id_ >= 0) rt_object_destroy(dev_.ctx(), id_); }
+    mat4 getModelMatrix() const { mat4 m = identity(); m = translate(m, Position); m = mul(m, mat4_cast(Rotation)); return scale(m, Scale); }
+    mat4 getInverseModelMatrix() const { return inverse(getModelMatrix()); }
+    void setPosition(vec3 p) { Position = p; }
+    void setRotation(quat q) { Rotation = q; }
+    void setScale(vec3 s) { Scale = s; }
+    void setMaterial(std::shared_ptr<Material> m) { materials.push_back(std::move(m)); } // setMaterialName without the global registry
+    bool isCompositeObject() const { return isComposite; }
+    const float* getMaxBound() const { return compositeMaxBounds; }
+    const float* getMinBound() const { return compositeMinBounds; }
+    bool getLoadSuccess() const { return loadSuccess; }
+    const std::vector<std::pair<std::shared_ptr<Mesh>, int>>& getMeshes() const { return meshes; }
+    const std::vector<std::shared_ptr<Material>>& getMaterials() const { return materials; }
+    void sendToGPU()
+    {
+        std::vector<rt_id> mi, ma; std::vector<int32_t> mx;
+        for (auto& p : meshes) { mi.push_back(p.first->id()); mx.push_back(p.second); }
+        for (auto& m : materials) ma.push_back(m->id());
+        if (id_ >= 0) { rt_object_destroy(dev_.ctx(), id_); id_ = -1; }
+        dev_.check(rt_object_create(dev_.ctx(), mi.data(), mx.data(), (int)mi.size(), ma.data(), (int)ma.size(), compositeMinBounds, compositeMaxBounds, &id_));
+    }
+    rt_id id() { if (id_ < 0) sendToGPU(); return id_; }
+protected:
+    void updateCompositeBounds()
+    {
+        if (!isComposite) { memcpy(compositeMaxBounds, meshes[0].first->getMaxBound(), 12); memcpy(compositeMinBounds, meshes[0].first->getMinBound(), 12); return; }
+        for (int k = 0; k < 3; k++) { compositeMaxBounds[k] = -FLT_MAX; compositeMinBounds[k] = FLT_MAX; }
+        for (auto& p : meshes)
+            for (int k = 0; k < 3; k++) { compositeMaxBounds[k] = fmaxf(p.first->getMaxBound()[k], compositeMaxBounds[k]); compositeMinBounds[k] = fminf(p.first->getMinBound()[k], compositeMinBounds[k]); }
+    }
+    Device& dev_;
+    vec3 Position; quat Rotation; vec3 Scale;
+    float compositeMaxBounds[3] = { 0, 0, 0 }, compositeMinBounds[3] = { 0, 0, 0 };
+    std::vector<std::pair<std::shared_ptr<Mesh>, int>> meshes;
+    std::vector<std::shared_ptr<Material>> materials;
+    bool isComposite = false, loadSuccess = false;
+    rt_id id_ = -1;
+};
+
+// Cube.hpp: 36 vertices / 12 triangles, UVs, no normals; the constructor drops its transform (Cube.hpp:8)
+class Cube : public DisplayObject {
+public:
+    explicit Cube(Device& dev, vec3 = {}, quat = {}, vec3 = { 1, 1, 1 }) : DisplayObject(dev)
+    {
+        static const signed char faces[6][4][3] = {
+            { { -1, -1, -1 }, { 1, -1, -1 }, { 1, 1, -1 }, { -1, 1, -1 } }, { { 1, -1, 1 }, { -1, -1, 1 }, { -1, 1, 1 }, { 1, 1, 1 } },
+            { { -1, -1, 1 }, { -1, -1, -1 }, { -1, 1, -1 }, { -1, 1, 1 } }, { { 1, -1, -1 }, { 1, -1, 1 }, { 1, 1, 1 }, { 1, 1, -1 } },
+            { { 1, -1, -1 }, { -1, -1, -1 }, { -1, -1, 1 }, { 1, -1, 1 } }, { { 1, 1, 1 }, { -1, 1, 1 }, { -1, 1, -1 }, { 1, 1, -1 } } };
+        static const int order[6] = { 0, 1, 2, 2, 3, 0 };
+        static const float cuv[4][2] = { { 0, 0 }, { 0, 1 }, { 1, 1 }, { 1, 0 } };
+        std::vector<float> v, uv; std::vector<int> idx;
+        for (auto& f : faces) for (int k : order) { for (int c = 0; c < 3; c++) v.push_back(0.5f * f[k][c]); uv.push_back(cuv[k][0]); uv.push_back(cuv[k][1]); }
+        for (int i = 0; i < 36; i++) idx.push_back(i);
+        meshes.push_back({ std::make_shared<Mesh>(dev, v, idx, uv, std::vector<float>()), 0 });
+        updateCompositeBounds();
+        loadSuccess = true;
+    }
+};
+
+// Sphere.hpp: 16x12 UV sphere, r = 0.5, normals = 2*position, PI = 3.14159f (Sphere.hpp:7)
+class Sphere : public DisplayObject {
+public:
+    explicit Sphere(Device& dev, vec3 position = {}, quat rotation = {}, vec3 scl = { 1, 1, 1 }) : DisplayObject(dev, position, rotation, scl)
+    {
+        const int SX = 16, SY = 12; const float PI = 3.14159f;
+        std::vector<float> v, n, uv; std::vector<int> idx;
+        auto s = [](float a) { return (float)std::sin((double)a); }; auto c = [](float a) { return (float)std::cos((double)a); }; // pinned: binary64, rounded once
+        for (int i = 0; i < SX; i++) { v.insert(v.end(), { 0.0f, -0.5f, 0.0f }); n.insert(n.end(), { 0.0f, -1.0f, 0.0f }); uv.push_back((float)(2 * i + 1) / (2 * SX)); uv.push_back(0.0f); }
+        for (int i = 1; i < SY; i++) for (int j = 0; j <= SX; j++) {
+            const float theta = (float)i / SY * PI, phi = (float)j / SX * 2 * PI;
+            const float x = 0.5f * s(theta) * c(phi), y = -0.5f * c(theta), z = 0.5f * s(theta) * s(phi);
+            v.insert(v.end(), { x, y, z }); n.insert(n.end(), { x * 2, y * 2, z * 2 }); uv.push_back((float)j / SX); uv.push_back((float)i / SY);
+        }
+        for (int i = 0; i < SX; i++) { v.insert(v.end(), { 0.0f, 0.5f, 0.0f }); n.insert(n.end(), { 0.0f, 1.0f, 0.0f }); uv.push_back((float)(2 * i + 1) / (2 * SX)); uv.push_back(1.0f); }
+        for (int i = 0; i < SX; i++) idx.insert(idx.end(), { i, i + SX + 1, i + SX });
+        for (int i = 0; i < SY - 2; i++) for (int j = 0; j < SX; j++) { const int a = SX + (SX + 1) * i + j, b = SX + (SX + 1) * (i + 1) + j; idx.insert(idx.end(), { a, b + 1, b, a, a + 1, b + 1 }); }
+        const int bottom = SX + (SX + 1) * (SY - 2);
+        for (int i = 0; i < SX; i++) idx.insert(idx.end(), { bottom + i, bottom + i + 1, bottom + i + 1 + SX });
+        meshes.push_back({ std::make_shared<Mesh>(dev, v, idx, uv, n), 0 });
+        updateCompositeBounds();
+        loadSuccess = true;
+    }
+};
+
+// What CustomModel (CustomModel.cpp:135-145) is after import: explicit (mesh, materialIndex) pairs
+class MeshObject : public DisplayObject {
+public:
+    MeshObject(Device& dev, std::vector<std::pair<std::shared_ptr<Mesh>, int>> m, std::vector<std::shared_ptr<Material>> mats, vec3 position = {},
+               quat rotation = {}, vec3 scl = { 1, 1, 1 }) : DisplayObject(dev, position, rotation, scl)
+    {
+        meshes = std::move(m); materials = std::move(mats);
+        isComposite = meshes.size() > 1;
+        if (!meshes.empty()) { updateCompositeBounds(); loadSuccess = true; }
+    }
+};
+
+// ---------------------------------------------------------------- Scene (Scene.hpp:41-176, Scene.cpp:3-29); iteration = insertion order
+class Scene {
+public:
+    explicit Scene(Device& dev) : dev_(dev) {}
+    bool addToScene(std::string name, std::shared_ptr<DisplayObject> object)
+    {
+        for (auto& p : objects_) if (p.first == name) return false;
+        objects_.push_back({ std::move(name), std::move(object) });
+        return true;
+    }
+    bool removeFromSceen(const std::string& name) // sic
+    {
+        for (auto it = objects_.begin(); it != objects_.end(); ++it) if (it->first == name) { objects_.erase(it); return true; }
+        return false;
+    }
+    std::vector<std::pair<std::string, std::shared_ptr<DisplayObject>>>& getObjects() { return objects_; }
+    void sendToGPU() { for (auto& p : objects_) p.second->sendToGPU(); }
+    // getGPUObjectDataVector: instance table = (model, inverse(model)) per object -> rt_scene_commit
+    void commit()
+    {
+        std::vector<rt_id> ids; std::vector<float> model, inv;
+        for (auto& p : objects_) {
+            ids.push_back(p.second->id());
+            const mat4 m = p.second->getModelMatrix(), im = inverse(m);
+            model.insert(model.end(), &m.c[0][0], &m.c[0][0] + 16); inv.insert(inv.end(), &im.c[0][0], &im.c[0][0] + 16);
+        }
+        dev_.check(rt_scene_commit(dev_.ctx(), ids.data(), model.data(), inv.data(), (int)ids.size()));
+    }
+private:
+    Device& dev_;
+    std::vector<std::pair<std::string, std::shared_ptr<DisplayObject>>> objects_;
+};
+
+// ---------------------------------------------------------------- Camera (Camera.hpp:16-132)
+class Camera {
+public:
+    Camera(Device& dev, vec3 position, quat rotation, float fov, float exposure) : dev_(dev), Position(position), Rotation(rotation), verticalFOV(fov), exposureValue(exposure) {}
+    void update() { if ((int)preTransformRays.size() != width * height * 4) calcRays(); }
+    // Camera::calcRays (Camera.hpp:46-70) without the upload
+    static void computeRays(int width, int height, float verticalFOV, std::vector<float>& out)
+    {
+        const float rad = (verticalFOV / 2) * 0.01745329251994329576923690768489f;
+        const float virtualHeight = (float)std::tan((double)rad) * 2; // pinned: tangent in binary64, rounded once
+        const float virtualWidth = virtualHeight * width / height;
+        const float wStep = virtualWidth / width, hStep = virtualHeight / height;
+        const float xOffset = wStep * (width / 2), yOffset = hStep * (height / 2);
+        out.assign((size_t)width * height * 4, 0.0f);
+        for (int j = 0; j < height; j++) for (int i = 0; i < width; i++) {
+            const float r = (float)((i * wStep) - xOffset), u = (float)((j * hStep) - yOffset);
+            const float tx = r * r, ty = u * u, tz = -1.0f * -1.0f, tw = 0.0f * 0.0f;
+            const float inv = 1.0f / std::sqrt((tx + ty) + (tz + tw)); // glm::normalize(vec4)
+            float* o = &out[((size_t)j * width + i) * 4];
+            o[0] = r * inv; o[1] = u * inv; o[2] = -1.0f * inv; o[3] = 0.0f * inv;
+        }
+    }
+    void calcRays()
+    {
+        computeRays(width, height, verticalFOV, preTransformRays);
+        dev_.check(rt_camera_set_rays(dev_.ctx(), preTransformRays.data(), width, height));
+    }
+    int getWidth() const { return width; }
+    int getHeight() const { return height; }
+    float getExposure() const { return exposureValue; }
+    vec3 getPosition() const { return Position; }
+    quat getRotation() const { return Rotation; }
+    void setPosition(vec3 p) { Position = p; }
+    void setRotation(quat q) { Rotation = q; }
+    void setHeight(int h) { height = h; }
+    void setWidth(int w) { width = w; }
+    const std::vector<float>& rays() const { return preTransformRays; }
+private:
+    Device& dev_;
+    vec3 Position; quat Rotation;
+    std::vector<float> preTransformRays;
+    int width = 0, height = 0;
+    float verticalFOV, exposureValue;
+};
+
+// ---------------------------------------------------------------- output: headless framebuffer (replaces RenderWindow.cpp:215-234, 389-421)
+class FrameBuffer {
+public:
+    FrameBuffer(Device& dev, int w, int h) : dev_(dev), w_(w), h_(h) { dev_.check(rt_framebuffer_create(dev_.ctx(), w, h, &id_)); }
+    ~FrameBuffer() { if (id_ >= 0) rt_framebuffer_destroy(dev_.ctx(), id_); }
+    FrameBuffer(const FrameBuffer&) = delete;
+    rt_id id() const { return id_; }
+    int width() const { return w_; }
+    int height() const { return h_; }
+    std::vector<float> read() const { std::vector<float> v((size_t)w_ * h_ * 4); dev_.check(rt_framebuffer_read(dev_.ctx(), id_, v.data())); return v; }
+    // takeScreenshot: the reference reads the sRGB-encoded back buffer and flips it; row 0 of the
+    // render buffer is the bottom of the picture
+    bool savePNG(const std::string& path) const
+    {
+        const std::vector<float> f = read();
+        std::vector<unsigned char> px((size_t)w_ * h_ * 4);
+        for (int y = 0; y < h_; y++) for (int x = 0; x < w_; x++) for (int c = 0; c < 4; c++) {
+            float v = f[((size_t)(h_ - 1 - y) * w_ + x) * 4 + c];
+            v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+            if (c < 3) v = v <= 0.0031308f ? 12.92f * v : 1.055f * std::pow(v, 1.0f / 2.4f) - 0.055f;
+            px[((size_t)y * w_ + x) * 4 + c] = (unsigned char)(v * 255.0f + 0.5f);
+        }
+        return png::encode(path, px.data(), (unsigned)w_, (unsigned)h_);
+    }
+private:
+    Device& dev_;
+    int w_, h_;
+    rt_id id_ = -1;
+};
+
+// ---------------------------------------------------------------- Raytracer / GPURaytracer (Raytracer.hpp:18-63, GPURaytracer.cu:24-74)
+class Raytracer {
+public:
+    void setBounceCount(int count) { bounceCount = count; }
+    void setMaxDistance(float distance) { maxDistance = distance; }
+    void setAOIntensity(float intensity) { aoIntensity = intensity; }
+    void setProgressiveRendering(bool progressive) { progressiveRendering = progressive; }
+    int getBounceCount() const { return bounceCount; }
+    float getMaxDistance() const { return maxDistance; }
+    float getAOIntensity() const { return aoIntensity; }
+    bool getProgressiveRendering() const { return progressiveRendering; }
+    int getSampleCount() const { return (int)sampleCount; }
+    void setSampleCount(int count) { sampleCount = (unsigned)count; }
+    void setAntiAliasingEnabled(bool enabled) { antiAliasingEnabled = enabled; }
+    bool getAntiAliasingEnabled() const { return antiAliasingEnabled; }
+    void setSkyLight(float pitch, float yaw, vec4 light, vec4 sky)
+    {
+        lightColor = light; skyColor = sky;
+        const float cp = (float)std::cos((double)pitch), sp = (float)std::sin((double)pitch), cy = (float)std::cos((double)yaw), sy = (float)std::sin((double)yaw);
+        lightDirection = { cp * cy, sp, cp * sy, 0.0f };
+    }
+    void setFrameCount(unsigned f) { frameCount = f; }
+protected:
+    int bounceCount = 3; float maxDistance = 100.0f; unsigned frameCount = 0, progressiveFrameCount = 0;
+    float aoIntensity = 0.01f; bool progressiveRendering = false, antiAliasingEnabled = true; unsigned sampleCount = 1;
+    vec4 lightDirection{ 1, 0, 0, 0 }, lightColor{ 1, 1, 1, 100 }, skyColor{ 0.5f, 0.5f, 1.0f, 0.3f }; // GUI defaults, RenderWindow.cpp:332-335
+};
+
+class GPURaytracer : public Raytracer {
+public:
+    explicit GPURaytracer(Device& dev) : dev_(dev) {}
+    // the reference rebuilds its instance table every frame (Scene.cpp:3-29); pass recommit = false for a static scene
+    void raytrace(Scene& s, Camera& c, FrameBuffer& o, bool recommit = true)
+    {
+        if (recommit) s.commit();
+        c.update();
+        rt_camera_params cam; const vec3 p = c.getPosition(); const quat q = c.getRotation();
+        cam.origin[0] = p.x; cam.origin[1] = p.y; cam.origin[2] = p.z; cam.origin[3] = 1.0f;
+        cam.rotation[0] = q.x; cam.rotation[1] = q.y; cam.rotation[2] = q.z; cam.rotation[3] = q.w;
+        cam.exposure = c.getExposure(); cam.width = c.getWidth(); cam.height = c.getHeight();
+        rt_renderer_params r{ bounceCount, maxDistance, aoIntensity, frameCount, progressiveFrameCount, antiAliasingEnabled ? 1 : 0, sampleCount };
+        rt_sky_params sky;
+        const vec4* src[3] = { &lightDirection, &lightColor, &skyColor }; float* dst[3] = { sky.direction, sky.lightColor, sky.skyColor };
+        for (int i = 0; i < 3; i++) { dst[i][0] = src[i]->x; dst[i][1] = src[i]->y; dst[i][2] = src[i]->z; dst[i][3] = src[i]->w; }
+        dev_.check(rt_render(dev_.ctx(), &cam, &r, &sky, rt_rect{ 0, 0, c.getWidth(), c.getHeight() }, o.id()));
+        dev_.check(rt_sync(dev_.ctx()));
+        frameCount++;
+        if (progressiveRendering) progressiveFrameCount++; else progressiveFrameCount = 0;
+    }
+private:
+    Device& dev_;
+};
+
+} // namespace rth
