@@ -12,7 +12,7 @@ import numpy as np
 from .scene import Camera, FlatScene, RenderSettings, Scene
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_amd.so")
+LIB_PATH = os.environ.get("RT_AMD_LIB", os.path.join(_HERE, "librt_amd.so"))  # override: timing-only ablation builds
 _LIB = None
 
 

@@ -10,6 +10,9 @@
 
 namespace {
 
+constexpr size_t kWorkBytes = sizeof(uint32_t) * 512;
+constexpr size_t kCntBytes = sizeof(unsigned long long) * rt::kCounterSlots * rt::kCounterStride;
+
 thread_local std::string g_createError;
 
 struct MeshRec {
@@ -58,6 +61,9 @@ struct rt_ctx {
     int optTraversal = 0;
     int optCounters = 0;
     int optAccumulate = 0;
+    int numCUs = 256;
+    uint32_t* dWork = nullptr;      // 8 tile counters (32 words apart) + redo count at word 256
+    uint32_t* dRedoList = nullptr; size_t redoCap = 0;
 };
 
 namespace {
@@ -175,9 +181,11 @@ int rt_ctx_create(int device, rt_ctx** out)
     RT_CHECK(nullptr, hipSetDevice(device));
     rt_ctx* c = new rt_ctx();
     c->device = device;
+    c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     hipError_t e = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->dCounters, 8 * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipHostMalloc((void**)&c->hCounters, 8 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->dCounters, kCntBytes);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->hCounters, kCntBytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->dWork, kWorkBytes);
     if (e == hipSuccess) e = hipEventCreate(&c->evBegin);
     if (e == hipSuccess) e = hipEventCreate(&c->evEnd);
     for (int i = 0; i < 16 && e == hipSuccess; i++) e = hipEventCreate(&c->slots[i]);
@@ -186,7 +194,7 @@ int rt_ctx_create(int device, rt_ctx** out)
         rt_ctx_destroy(c);
         return fail(nullptr, RT_ERR_HIP, m);
     }
-    memset(c->hCounters, 0, 8 * sizeof(unsigned long long));
+    memset(c->hCounters, 0, kCntBytes);
     c->stream = c->ownStream;
     *out = c;
     return RT_OK;
@@ -202,7 +210,7 @@ int rt_ctx_destroy(rt_ctx* c)
     for (auto& t : c->textures) if (t.live) hipFree(t.data);
     for (auto& f : c->fbs) if (f.live) { if (f.owned) hipFree(f.data); hipFree(f.ids); }
     rt::free_scene(c->built);
-    hipFree(c->dObjects); hipFree(c->dMaterials); hipFree(c->dTextures); hipFree(c->dRays); hipFree(c->dCounters);
+    hipFree(c->dObjects); hipFree(c->dMaterials); hipFree(c->dTextures); hipFree(c->dRays); hipFree(c->dCounters); hipFree(c->dWork); hipFree(c->dRedoList);
     if (c->hCounters) hipHostFree(c->hCounters);
     if (c->evBegin) hipEventDestroy(c->evBegin);
     if (c->evEnd) hipEventDestroy(c->evEnd);
@@ -229,7 +237,7 @@ int rt_set_option(rt_ctx* c, int option, int value)
     case RT_OPT_COUNTERS: c->optCounters = value ? 1 : 0; return RT_OK;
     case RT_OPT_ACCUMULATE_STATS:
         c->optAccumulate = value ? 1 : 0;
-        RT_CHECK(c, hipMemsetAsync(c->dCounters, 0, 8 * sizeof(unsigned long long), c->stream));
+        RT_CHECK(c, hipMemsetAsync(c->dCounters, 0, kCntBytes, c->stream));
         return RT_OK;
     default: return fail(c, RT_ERR_INVALID, "unknown option");
     }
@@ -249,9 +257,12 @@ int rt_get_stats(rt_ctx* c, rt_stats* out)
     memset(out, 0, sizeof(*out));
     RT_CHECK(c, hipStreamSynchronize(c->stream));
     if (c->renderedOnce) {
-        RT_CHECK(c, hipMemcpy(c->hCounters, c->dCounters, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        out->rays = c->hCounters[0]; out->slow_path = c->hCounters[1];
-        out->node_visits = c->hCounters[2]; out->tri_tests = c->hCounters[3]; out->hits = c->hCounters[4];
+        RT_CHECK(c, hipMemcpy(c->hCounters, c->dCounters, kCntBytes, hipMemcpyDeviceToHost));
+        unsigned long long sum[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        for (int sl = 0; sl < rt::kCounterSlots; sl++)
+            for (int k = 0; k < 8; k++) sum[k] += c->hCounters[(size_t)sl * rt::kCounterStride + k];
+        out->rays = sum[0]; out->slow_path = sum[1];
+        out->node_visits = sum[2]; out->tri_tests = sum[3]; out->hits = sum[4];
         float ms = 0.0f;
         RT_CHECK(c, hipEventElapsedTime(&ms, c->evBegin, c->evEnd));
         out->kernel_ms = ms;
@@ -611,10 +622,20 @@ int rt_render(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* 
     memcpy(a.skyDir, sky->direction, 16); memcpy(a.lightColor, sky->lightColor, 16); memcpy(a.skyColor, sky->skyColor, 16);
     a.x0 = tile.x0; a.y0 = tile.y0; a.x1 = tile.x1; a.y1 = tile.y1;
     a.fb = f.data; a.ids = f.idsEnabled ? f.ids : nullptr; a.counters = c->dCounters;
+    const size_t tilePixels = (size_t)(tile.x1 - tile.x0) * (size_t)(tile.y1 - tile.y0);
+    if (tilePixels > c->redoCap) { // grows only when a larger tile than ever before is rendered
+        RT_CHECK(c, hipStreamSynchronize(c->stream));
+        hipFree(c->dRedoList); c->dRedoList = nullptr; c->redoCap = 0;
+        RT_CHECK(c, hipMalloc((void**)&c->dRedoList, sizeof(uint32_t) * tilePixels));
+        c->redoCap = tilePixels;
+    }
+    a.tileCounters = c->dWork; a.redoCount = c->dWork + 256; a.redoList = c->dRedoList;
+    a.pixelList = nullptr; a.pixelCount = nullptr;
+    RT_CHECK(c, hipMemsetAsync(c->dWork, 0, kWorkBytes, c->stream));
 
-    if (!c->optAccumulate) RT_CHECK(c, hipMemsetAsync(c->dCounters, 0, 8 * sizeof(unsigned long long), c->stream));
+    if (!c->optAccumulate) RT_CHECK(c, hipMemsetAsync(c->dCounters, 0, kCntBytes, c->stream));
     RT_CHECK(c, hipEventRecord(c->evBegin, c->stream));
-    rt::launch_render(a, c->optTraversal, c->stream);
+    rt::launch_render(a, c->optTraversal, c->numCUs, c->stream);
     RT_CHECK(c, hipGetLastError());
     RT_CHECK(c, hipEventRecord(c->evEnd, c->stream));
     c->renderedOnce = true;
@@ -631,7 +652,7 @@ int rt_trace_rays(rt_ctx* c, const float* rays, int32_t n, uint32_t* out)
     RT_CHECK(c, hipMalloc((void**)&dr, 32 * (size_t)n));
     hipError_t e = hipMalloc((void**)&dout, 16 * (size_t)n);
     if (e == hipSuccess) e = hipMemcpyAsync(dr, rays, 32 * (size_t)n, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(c->dCounters, 0, 8 * sizeof(unsigned long long), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->dCounters, 0, kCntBytes, c->stream);
     if (e == hipSuccess) {
         rt::launch_trace_rays(scene_view(c), dr, n, dout, c->dCounters, c->optTraversal, c->stream);
         e = hipGetLastError();

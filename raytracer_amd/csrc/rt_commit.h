@@ -36,7 +36,7 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
                  hipStream_t stream, std::string& err);
 void free_scene(BuiltScene& s);
 
-void launch_render(const RenderArgs& a, int mode, hipStream_t stream);
+void launch_render(const RenderArgs& a, int mode, int numCUs, hipStream_t stream);
 void launch_trace_rays(const SceneView& s, const float4* rays, int n, uint4* out, unsigned long long* counters, int mode,
                        hipStream_t stream);
 void launch_detmath(int op, const float* in, int n, float* out, hipStream_t stream);

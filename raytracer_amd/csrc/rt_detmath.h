@@ -77,6 +77,9 @@ __device__ __forceinline__ float rsqrt_f(float x) { return 1.0f / __builtin_sqrt
 
 __device__ __forceinline__ float log_f(float x)
 {
+#ifdef RT_ABLATE_MATH
+    return x * 0.5f - 1.0f; // timing-only build, wrong on purpose
+#endif
     if (x != x) return x;
     if (x < 0.0f) return __builtin_nanf("");
     if (x == 0.0f) return -__builtin_inff();
@@ -86,6 +89,9 @@ __device__ __forceinline__ float log_f(float x)
 
 __device__ __forceinline__ float exp_f(float x)
 {
+#ifdef RT_ABLATE_MATH
+    return x * 0.25f + 0.5f;
+#endif
     if (x != x) return x;
     if (x > 89.0f) return __builtin_inff();
     if (x < -104.0f) return 0.0f;
@@ -94,6 +100,9 @@ __device__ __forceinline__ float exp_f(float x)
 
 __device__ __forceinline__ float cos_f(float x)
 {
+#ifdef RT_ABLATE_MATH
+    return x * 0.1f - 0.3f;
+#endif
     if (x != x || x == __builtin_inff() || x == -__builtin_inff()) return __builtin_nanf("");
     const double xd = (double)x;
     const double kf = floor(xd * kTwoOverPi + 0.5);
@@ -130,6 +139,9 @@ __device__ __forceinline__ float cos_f(float x)
 
 __device__ __forceinline__ float pow_f(float x, float y)
 {
+#ifdef RT_ABLATE_MATH
+    return x * x * y * 1e-3f;
+#endif
     if (x != x || y != y) return __builtin_nanf("");
     if (y == 0.0f) return 1.0f;
     if (x < 0.0f) return __builtin_nanf("");

@@ -14,6 +14,10 @@ namespace rt {
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
 constexpr int kLeafMax = 4;        // triangles per BVH leaf
 constexpr int kStackDepth = 64;    // >= 30 Morton bits + 24 index bits + margin
+constexpr int kLdsStack = 24;      // entries per lane kept in LDS; deeper entries spill to scratch
+constexpr int kBlock = 256;        // workgroup size of every tracing kernel
+constexpr int kCounterSlots = 256; // statistics counters are striped over this many 128-byte lines
+constexpr int kCounterStride = 16; // u64 per slot
 
 // 48 B: one world-space triangle, three 16-byte loads.  Two arrays of these exist: `triRef`
 // in reference order (object, mesh, triangle: index = gid) and `triLeaf` in BVH leaf order.
@@ -108,6 +112,14 @@ struct RenderArgs {
     uint4* ids;                // may be null
     unsigned long long* counters; // [0] rays, [1] slow-path rays, [2] node visits, [3] tri tests, [4] shaded hits (8 slots)
     int32_t tilesX, tilesY;
+    // persistent path kernel: 8x8-pixel tiles handed out through 8 striped counters
+    uint32_t* tileCounters;       // 8 counters, 32 words apart
+    int32_t tiles8X, tiles8Y;
+    // pixels whose result depends on the exact in-order emulation are re-rendered by a second launch
+    uint32_t* redoList;           // pixel indices y*width + x
+    uint32_t* redoCount;
+    const uint32_t* pixelList;    // non-null: render these pixels instead of the tile
+    const uint32_t* pixelCount;
 };
 
 } // namespace rt

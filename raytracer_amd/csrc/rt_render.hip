@@ -57,6 +57,9 @@ __device__ __forceinline__ float random_value(uint32_t& seed)
     seed = seed * 747796405u + 2891336453u;
     uint32_t r = ((seed >> ((seed >> 28) + 4u)) ^ seed) * 277803737u;
     r = (r >> 22) ^ r;
+#ifdef RT_ABLATE_RNG
+    return (float)r * 2.3283064e-10f; // timing-only build
+#endif
     return (float)((double)r / 4294967295.0);
 }
 // :827-833
@@ -233,87 +236,166 @@ __device__ __forceinline__ uint32_t seg_hash(uint32_t obj, uint32_t mesh, uint32
 }
 
 struct LaneStats {
-    unsigned long long rays, slow, triBrute, hits;
+    uint32_t rays, slow, triBrute, hits;
     BvhCounters bvh;
 };
 
+// MODE 0: BVH, rays inside the tie band only raise `danger` (hot kernel)
+// MODE 1: brute force in reference order
+// MODE 2: the reference loop with the BVH as a culling device only (redo launch)
+// MODE 3: BVH with the exact path inline (rt_trace_rays)
 template <int MODE>
-__device__ __forceinline__ Hit closest_hit(const SceneView& s, Ray& ray, uint32_t* stack, LaneStats& st)
+__device__ __forceinline__ Hit closest_hit(const SceneView& s, Ray& ray, const Stack& stack, LaneStats& st, bool& danger)
 {
     st.rays++;
     if (MODE == 1) return trace_brute(s, ray, st.triBrute);
-    return trace_bvh(s, ray, stack, st.bvh, st.slow);
+    if (MODE == 2) return trace_bvh_exact_all(s, ray, stack, st.bvh);
+    if (MODE == 3) return trace_bvh<true>(s, ray, stack, st.bvh, st.slow, danger);
+    return trace_bvh<false>(s, ray, stack, st.bvh, st.slow, danger);
 }
 
-// :165-245 for one sample; returns the un-exposed radiance
-template <int MODE>
-__device__ __forceinline__ V4 trace_path(const RenderArgs& a, Ray& ray, uint32_t& seed, uint32_t sample, uint32_t* stack,
-                                         LaneStats& st, uint32_t& checksum, uint32_t* primary)
+struct PathAcc {
+    float ox, oy, oz;   // outgoingLight
+    float bx, by, bz;   // betaAccumulation
+};
+
+// One iteration of the bounce loop (:172-242) after the closest-hit query.  Returns true when
+// the path continues with the updated ray.
+__device__ __forceinline__ bool shade_segment(const RenderArgs& a, const Hit& h, Ray& ray, uint32_t& seed, uint32_t sample,
+                                              int i, PathAcc& p, LaneStats& st, uint32_t& checksum, uint32_t* primary)
 {
-    V4 out = mk4(0.0f, 0.0f, 0.0f, 1.0f);
-    V4 beta = mk4(1.0f, 1.0f, 1.0f, 1.0f);
-    for (int i = 0; i < a.bounceCount; i++) {
-        const Hit h = closest_hit<MODE>(a.scene, ray, stack, st);
-        if (h.gid == kNoHit) {
-            checksum += seg_hash(kNoHit, kNoHit, kNoHit, sample, (uint32_t)i);
-            const V4 dir = mk4(ray.dx, ray.dy, ray.dz, 0.0f);
-            const V4 miss = sky_light(dir, a);
-            out.x += miss.x * miss.w * beta.x;
-            out.y += miss.y * miss.w * beta.y;
-            out.z += miss.z * miss.w * beta.z;
-            break;
-        }
-        uint32_t ho, hm, ht;
-        st.hits++;
-        const Surface sf = shade_surface(a.scene, h, ho, hm, ht);
-        checksum += seg_hash(ho, hm, ht, sample, (uint32_t)i);
-        if (i == 0 && sample == 0) { primary[0] = ho; primary[1] = hm; primary[2] = ht; }
-
-        if (i == 0) { // ambient term, AO is the constant (1,1,1) on the device path (Material.cu:41-44)
-            out.x += 1.0f * sf.albedo.x * a.aoIntensity;
-            out.y += 1.0f * sf.albedo.y * a.aoIntensity;
-            out.z += 1.0f * sf.albedo.z * a.aoIntensity;
-        }
-        out.x += sf.emission.x * sf.emission.w * beta.x;
-        out.y += sf.emission.y * sf.emission.w * beta.y;
-        out.z += sf.emission.z * sf.emission.w * beta.z;
-
-        if (i < a.bounceCount - 1) {
-            const float attenuation = 1.0f;
-            const V4 N = sf.normal;
-            const V4 D = mk4(ray.dx, ray.dy, ray.dz, 0.0f);
-            const V4 diffuseDir = random_cosine_hemi(seed, N);
-            const V4 specularDir = reflect4(D, N);
-            const V4 L = normalize4(lerp4(specularDir, diffuseDir, sf.roughness));
-            const V4 V = mk4(-D.x, -D.y, -D.z, D.w);
-            const V4 H = normalize4(mk4(L.x + V.x, L.y + V.y, L.z + V.z, 0.0f));
-            const V4 F0 = lerp4(mk4(0.04f, 0.04f, 0.04f, 1.0f), sf.albedo, sf.metal);
-
-            const float NDF = distribution_ggx(N, H, sf.roughness);
-            const float ndv = rtd::fmax_f(dot3(N, V), 0.0f);
-            const float ndl = rtd::fmax_f(dot3(N, L), 0.0f);
-            const float G = geometry_schlick(ndv, sf.roughness) * geometry_schlick(ndl, sf.roughness);
-            const float cosT = rtd::fmax_f(dot3(H, V), 0.0f);
-            const float pw = rtd::pow_f(1.0f - rtd::fmin_f(cosT, 1.0f), 5.0f);
-            const float Fx = F0.x + (1.0f - F0.x) * pw, Fy = F0.y + (1.0f - F0.y) * pw, Fz = F0.z + (1.0f - F0.z) * pw;
-
-            const float mc = 1.0f - sf.metal;
-            const float kDx = (1.0f - Fx) * mc, kDy = (1.0f - Fy) * mc, kDz = (1.0f - Fz) * mc;
-            const float denominator = 4.0f * ndv * ndl + 0.0001f;
-            const float spx = (NDF * G * Fx) / denominator, spy = (NDF * G * Fy) / denominator, spz = (NDF * G * Fz) / denominator;
-
-            beta.x *= (kDx * sf.albedo.x / kPi + spx) * attenuation * ndl;
-            beta.y *= (kDy * sf.albedo.y / kPi + spy) * attenuation * ndl;
-            beta.z *= (kDz * sf.albedo.z / kPi + spz) * attenuation * ndl;
-
-            const float nudge = 0.0001f;
-            ray.ox = sf.position.x + N.x * nudge;
-            ray.oy = sf.position.y + N.y * nudge;
-            ray.oz = sf.position.z + N.z * nudge;
-            ray.dx = L.x; ray.dy = L.y; ray.dz = L.z;
-        }
+    if (h.gid == kNoHit) {
+        checksum += seg_hash(kNoHit, kNoHit, kNoHit, sample, (uint32_t)i);
+        const V4 dir = mk4(ray.dx, ray.dy, ray.dz, 0.0f);
+        const V4 miss = sky_light(dir, a);
+        p.ox += miss.x * miss.w * p.bx;
+        p.oy += miss.y * miss.w * p.by;
+        p.oz += miss.z * miss.w * p.bz;
+        return false;
     }
-    return out;
+    uint32_t ho, hm, ht;
+    st.hits++;
+    const Surface sf = shade_surface(a.scene, h, ho, hm, ht);
+    checksum += seg_hash(ho, hm, ht, sample, (uint32_t)i);
+    if (i == 0 && sample == 0) { primary[0] = ho; primary[1] = hm; primary[2] = ht; }
+
+    if (i == 0) { // ambient term, AO is the constant (1,1,1) on the device path (Material.cu:41-44)
+        p.ox += 1.0f * sf.albedo.x * a.aoIntensity;
+        p.oy += 1.0f * sf.albedo.y * a.aoIntensity;
+        p.oz += 1.0f * sf.albedo.z * a.aoIntensity;
+    }
+    p.ox += sf.emission.x * sf.emission.w * p.bx;
+    p.oy += sf.emission.y * sf.emission.w * p.by;
+    p.oz += sf.emission.z * sf.emission.w * p.bz;
+
+    if (!(i < a.bounceCount - 1)) return false;
+
+    const float attenuation = 1.0f;
+    const V4 N = sf.normal;
+    const V4 D = mk4(ray.dx, ray.dy, ray.dz, 0.0f);
+    const V4 diffuseDir = random_cosine_hemi(seed, N);
+    const V4 specularDir = reflect4(D, N);
+    const V4 L = normalize4(lerp4(specularDir, diffuseDir, sf.roughness));
+    const V4 V = mk4(-D.x, -D.y, -D.z, D.w);
+    const V4 H = normalize4(mk4(L.x + V.x, L.y + V.y, L.z + V.z, 0.0f));
+    const V4 F0 = lerp4(mk4(0.04f, 0.04f, 0.04f, 1.0f), sf.albedo, sf.metal);
+
+    const float NDF = distribution_ggx(N, H, sf.roughness);
+    const float ndv = rtd::fmax_f(dot3(N, V), 0.0f);
+    const float ndl = rtd::fmax_f(dot3(N, L), 0.0f);
+    const float G = geometry_schlick(ndv, sf.roughness) * geometry_schlick(ndl, sf.roughness);
+    const float cosT = rtd::fmax_f(dot3(H, V), 0.0f);
+    const float pw = rtd::pow_f(1.0f - rtd::fmin_f(cosT, 1.0f), 5.0f);
+    const float Fx = F0.x + (1.0f - F0.x) * pw, Fy = F0.y + (1.0f - F0.y) * pw, Fz = F0.z + (1.0f - F0.z) * pw;
+
+    const float mc = 1.0f - sf.metal;
+    const float kDx = (1.0f - Fx) * mc, kDy = (1.0f - Fy) * mc, kDz = (1.0f - Fz) * mc;
+    const float denominator = 4.0f * ndv * ndl + 0.0001f;
+    const float spx = (NDF * G * Fx) / denominator, spy = (NDF * G * Fy) / denominator, spz = (NDF * G * Fz) / denominator;
+
+    p.bx *= (kDx * sf.albedo.x / kPi + spx) * attenuation * ndl;
+    p.by *= (kDy * sf.albedo.y / kPi + spy) * attenuation * ndl;
+    p.bz *= (kDz * sf.albedo.z / kPi + spz) * attenuation * ndl;
+
+    const float nudge = 0.0001f;
+    ray.ox = sf.position.x + N.x * nudge;
+    ray.oy = sf.position.y + N.y * nudge;
+    ray.oz = sf.position.z + N.z * nudge;
+    ray.dx = L.x; ray.dy = L.y; ray.dz = L.z;
+    return true;
+}
+
+// setupRay (:140-163)
+__device__ __forceinline__ Ray setup_ray(const RenderArgs& a, int x, int y, uint32_t& seed)
+{
+    Ray ray;
+    ray.ox = a.camOrigin[0]; ray.oy = a.camOrigin[1]; ray.oz = a.camOrigin[2];
+    ray.maxDist = a.maxDistance;
+    V4 d;
+    if (a.antiAliasing) {
+        const float xf = (float)x + random_value(seed) - 0.5f;
+        const float yf = (float)y + random_value(seed) - 0.5f;
+        d = tex2d_rays(a.rays, a.width, a.height, xf, yf);
+    } else {
+        d = tex2d_rays(a.rays, a.width, a.height, (float)x, (float)y);
+    }
+    d = normalize4(rotate_q(d, a.camRotation));
+    ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
+    return ray;
+}
+
+__device__ __forceinline__ uint32_t sample_seed(const RenderArgs& a, int x, int y, uint32_t sidx)
+{
+    return (uint32_t)x + (uint32_t)y * (uint32_t)a.width + sidx * 34673804u + a.frameCount * 719393u; // :94
+}
+
+// :117-137: divide, clamp, progressive running mean, store
+__device__ __forceinline__ void write_pixel(const RenderArgs& a, int x, int y, float r, float g, float b, const uint32_t* primary,
+                                            uint32_t checksum)
+{
+    const float spp = (float)a.sampleCount;
+    r /= spp; g /= spp; b /= spp;
+    r = rtd::fmin_f(rtd::fmax_f(r, 0.0f), 1.0f);
+    g = rtd::fmin_f(rtd::fmax_f(g, 0.0f), 1.0f);
+    b = rtd::fmin_f(rtd::fmax_f(b, 0.0f), 1.0f);
+    const size_t pix = (size_t)y * (size_t)a.width + (size_t)x;
+    if (a.progressiveFrameCount != 0) {
+        const float4 prev = a.fb[pix];
+        const float n = (float)a.progressiveFrameCount, n1 = (float)(a.progressiveFrameCount + 1u);
+        r = (r + prev.x * n) / n1;
+        g = (g + prev.y * n) / n1;
+        b = (b + prev.z * n) / n1;
+    }
+    a.fb[pix] = make_float4(r, g, b, 1.0f);
+    if (a.ids) a.ids[pix] = make_uint4(primary[0], primary[1], primary[2], checksum);
+}
+
+// statistics: wave shuffle -> LDS -> one global atomic per workgroup and counter, striped over
+// kCounterSlots cache lines (a single hot word saturates at ~88 atomics/us on MI355X and was the
+// whole frame time of a sky-only frame before this)
+__device__ __forceinline__ void flush_stats(const RenderArgs& a, const LaneStats& st, uint32_t* wgCnt)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t v0 = st.rays, v1 = st.slow, v2 = st.bvh.nodes, v3 = st.bvh.tris + st.triBrute, v4 = st.hits;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        v0 += __shfl_xor(v0, off);
+        v1 += __shfl_xor(v1, off);
+        v2 += __shfl_xor(v2, off);
+        v3 += __shfl_xor(v3, off);
+        v4 += __shfl_xor(v4, off);
+    }
+    if (threadIdx.x < 8) wgCnt[threadIdx.x] = 0;
+    __syncthreads();
+    if (lane == 0) {
+        atomicAdd(&wgCnt[0], v0); atomicAdd(&wgCnt[1], v1); atomicAdd(&wgCnt[2], v2);
+        atomicAdd(&wgCnt[3], v3); atomicAdd(&wgCnt[4], v4);
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const uint32_t v = wgCnt[threadIdx.x];
+        if (v) atomicAdd(a.counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride + threadIdx.x, (unsigned long long)v);
+    }
 }
 
 // bijective XCD-aware remap: workgroups b, b+8, b+16, ... share an XCD; give each XCD a
@@ -325,7 +407,176 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
     return base + i;
 }
 
-// LOG2L: log2 of the sample lanes per pixel (0, 1, 2).  MODE: 0 BVH, 1 brute force.
+// ------------------------------------------------------------------------------------------------
+// Hot kernel: persistent wavefronts with path regeneration.
+//
+// A lane owns one PIXEL at a time and walks all of its samples in the reference's summation order
+// (z-lane major: s = z, z+4, z+8, ... for z = 0..3; the per-z partial sums are then added in z
+// order, GPURaytracer.cu:88-116), so no cross-lane reduction is needed.  The wave runs one loop:
+//   (1) lanes whose path ended start their next sample, or finish their pixel and take a new
+//       one from the wave's pool (an 8x8 tile fetched with ONE atomic per 64 pixels from 8 striped
+//       counters; the workgroups that share an XCD drain the same contiguous band of tiles first);
+//   (2) every lane that holds a ray runs one closest-hit query;
+//   (3) miss -> sky, hit -> shade and spawn the bounce ray.
+// All 64 lanes therefore carry a ray into every traversal, whatever the path lengths; in the
+// reference (and in the tile kernel below) a wave keeps paying for its longest path while the lanes
+// that missed sit idle.
+__global__ __launch_bounds__(256, 4) void path_kernel(const RenderArgs a)
+{
+    __shared__ uint32_t ldsStack[kLdsStack * kBlock];
+    __shared__ uint32_t poolSlot[kBlock];
+    __shared__ uint32_t wgCnt[8];
+    uint32_t ovf[kStackDepth - kLdsStack];
+    Stack stack; stack.lds = ldsStack + threadIdx.x; stack.ovf = ovf;
+    const int lane = threadIdx.x & 63;
+    uint32_t* slot = poolSlot + (threadIdx.x & ~63);
+
+    LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
+
+    // wave-uniform work pool
+    const uint32_t nTiles = (uint32_t)a.tiles8X * (uint32_t)a.tiles8Y;
+    const uint32_t part0 = blockIdx.x & 7u;
+    uint32_t exhausted = 0;       // bit p: partition p has no tile left
+    unsigned long long poolMask = 0;
+    int poolX = 0, poolY = 0;
+    bool noMore = false;
+
+    // lane state
+    bool hasPixel = false, hasPath = false, flagged = false;
+    int x = 0, y = 0;
+    uint32_t z = 0, iter = 0, seed = 0, checksum = 0;
+    uint32_t rays0 = 0, hits0 = 0;  // statistics at pixel start: a flagged pixel is counted by the redo launch instead
+    int bounce = 0;
+    uint32_t primary[3] = { kNoHit, kNoHit, kNoHit };
+    float pr = 0.0f, pg = 0.0f, pb = 0.0f;   // partial sum of the current z lane
+    float tr = 0.0f, tg = 0.0f, tb = 0.0f;   // sum over z lanes
+    PathAcc acc; acc.ox = acc.oy = acc.oz = 0.0f; acc.bx = acc.by = acc.bz = 1.0f;
+    Ray ray; ray.ox = ray.oy = ray.oz = ray.dx = ray.dy = ray.dz = 0.0f; ray.maxDist = 0.0f;
+    const uint32_t spp = a.sampleCount;
+
+    for (;;) {
+        // ---- (1a) lanes whose path ended: next sample of the pixel, or the pixel is finished
+        if (hasPixel && !hasPath) {
+            iter++;
+            if (iter * 4u + z >= spp) {             // this z lane has no sample left (:90)
+                tr += pr; tg += pg; tb += pb;       // :112-116, z order
+                pr = pg = pb = 0.0f;
+                z++; iter = 0;
+                if (z >= 4u || z >= spp) {
+                    for (; z < 4u; z++) { tr += 0.0f; tg += 0.0f; tb += 0.0f; } // slots never written read as 0
+                    if (flagged) {
+                        st.rays = rays0; st.hits = hits0;
+                        const uint32_t k = atomicAdd(a.redoCount, 1u);
+                        a.redoList[k] = (uint32_t)y * (uint32_t)a.width + (uint32_t)x;
+                    } else {
+                        write_pixel(a, x, y, tr, tg, tb, primary, checksum);
+                    }
+                    hasPixel = false;
+                }
+            }
+        }
+        // ---- (1b) lanes without a pixel take one from the wave's pool
+        unsigned long long need = __ballot(!hasPixel && !noMore);
+        while (need != 0ull) {
+            if (poolMask == 0ull) {
+                int t = -1;
+                if (lane == 0) {
+                    for (uint32_t k = 0; k < 8u && t < 0; k++) {
+                        const uint32_t p = (part0 + k) & 7u;
+                        if (exhausted & (1u << p)) continue;
+                        const uint32_t lo = (uint32_t)(((unsigned long long)nTiles * p) >> 3);
+                        const uint32_t hi = (uint32_t)(((unsigned long long)nTiles * (p + 1u)) >> 3);
+                        const uint32_t i = atomicAdd(a.tileCounters + p * 32u, 1u);
+                        if (i < hi - lo) t = (int)(lo + i); else exhausted |= 1u << p;
+                    }
+                }
+                t = __shfl(t, 0);
+                if (t < 0) { noMore = true; break; }
+                poolX = a.x0 + (t % a.tiles8X) * 8;
+                poolY = a.y0 + (t / a.tiles8X) * 8;
+                const bool valid = poolX + (lane & 7) < a.x1 && poolY + (lane >> 3) < a.y1;
+                poolMask = __ballot(valid);
+                if (poolMask == 0ull) continue;
+            }
+            // the k-th needing lane takes the k-th free pixel of the tile
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const bool isFree = (poolMask >> lane) & 1ull;
+            if (isFree) slot[__popcll(poolMask & below)] = (uint32_t)lane;
+            const int rank = __popcll(need & below);
+            const int avail = __popcll(poolMask);
+            const bool want = (need >> lane) & 1ull;
+            __builtin_amdgcn_wave_barrier();
+            if (want && rank < avail) {
+                const uint32_t bit = slot[rank];
+                x = poolX + (int)(bit & 7u); y = poolY + (int)(bit >> 3);
+                hasPixel = true; flagged = false;
+                rays0 = st.rays; hits0 = st.hits;
+                z = 0; iter = 0; checksum = 0;
+                primary[0] = primary[1] = primary[2] = kNoHit;
+                pr = pg = pb = 0.0f; tr = tg = tb = 0.0f;
+            }
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long taken = __ballot(want && rank < avail);
+            // clear the bits that were handed out: they are the lowest popc(taken) set bits
+            int k = __popcll(taken);
+            unsigned long long m = poolMask;
+            while (k-- > 0) m &= m - 1ull;
+            poolMask = m;
+            need = __ballot(!hasPixel && !noMore);
+        }
+        // ---- (1c) start the next sample
+        if (hasPixel && !hasPath) {
+            const uint32_t sidx = iter * 4u + z;
+            seed = sample_seed(a, x, y, sidx);
+            ray = setup_ray(a, x, y, seed);
+            acc.ox = acc.oy = acc.oz = 0.0f; acc.bx = acc.by = acc.bz = 1.0f;
+            bounce = 0;
+            hasPath = a.bounceCount > 0;
+            if (!hasPath) { // bounceCount <= 0: the bounce loop does not run, radiance 0
+                pr += 1.0f - rtd::exp_f(-0.0f * a.exposure);
+                pg += 1.0f - rtd::exp_f(-0.0f * a.exposure);
+                pb += 1.0f - rtd::exp_f(-0.0f * a.exposure);
+            }
+        }
+        if (__ballot(hasPixel) == 0ull) break; // every lane is idle and no tile is left
+
+        // ---- (2) + (3) one path segment for every lane that holds a ray
+        if (hasPath) {
+            bool danger = false;
+            const Hit h = closest_hit<0>(a.scene, ray, stack, st, danger);
+            flagged = flagged || danger;
+            const uint32_t sidx = iter * 4u + z;
+            const bool more = shade_segment(a, h, ray, seed, sidx, bounce, acc, st, checksum, primary);
+            bounce++;
+            if (!more) {
+                hasPath = false;
+                // exposureCorrection (:690-698), per sample, then :102-104
+                pr += 1.0f - rtd::exp_f(-acc.ox * a.exposure);
+                pg += 1.0f - rtd::exp_f(-acc.oy * a.exposure);
+                pb += 1.0f - rtd::exp_f(-acc.oz * a.exposure);
+            }
+        }
+    }
+    flush_stats(a, st, wgCnt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tile / list kernel: one thread per (pixel, z lane) as in the reference, nested sample and bounce
+// loops.  Used for the brute-force mode (MODE 1, whole tile) and for the redo launch (MODE 2,
+// pixel list written by path_kernel).  LOG2L: log2 of the sample lanes per pixel (0, 1, 2).
+template <int MODE>
+__device__ __forceinline__ V4 trace_path(const RenderArgs& a, Ray& ray, uint32_t& seed, uint32_t sample, const Stack& stack,
+                                         LaneStats& st, uint32_t& checksum, uint32_t* primary)
+{
+    PathAcc p; p.ox = p.oy = p.oz = 0.0f; p.bx = p.by = p.bz = 1.0f;
+    for (int i = 0; i < a.bounceCount; i++) {
+        bool danger = false;
+        const Hit h = closest_hit<MODE>(a.scene, ray, stack, st, danger);
+        if (!shade_segment(a, h, ray, seed, sample, i, p, st, checksum, primary)) break;
+    }
+    return mk4(p.ox, p.oy, p.oz, 1.0f);
+}
+
 template <int LOG2L, int MODE>
 __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a)
 {
@@ -333,105 +584,77 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a)
     constexpr int TW = (L == 4) ? 4 : 8;   // wave tile in pixels
     constexpr int TH = (L == 1) ? 8 : 4;
     constexpr int BW = 2 * TW, BH = 2 * TH; // workgroup = 2x2 waves
+    constexpr int PIX_PER_WG = 256 / L;
 
-    const uint32_t nBlocks = (uint32_t)a.tilesX * (uint32_t)a.tilesY;
-    const uint32_t tile = xcd_remap(blockIdx.x, nBlocks);
-    const int ty = (int)(tile / (uint32_t)a.tilesX), tx = (int)(tile % (uint32_t)a.tilesX);
+    __shared__ uint32_t ldsStack[kLdsStack * kBlock];
+    __shared__ uint32_t wgCnt[8];
+    uint32_t ovf[kStackDepth - kLdsStack];
+    Stack stack; stack.lds = ldsStack + threadIdx.x; stack.ovf = ovf;
+    LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
+
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t z = (uint32_t)(lane & (L - 1));
     const int p = lane >> LOG2L;
-    const int x = a.x0 + tx * BW + (wave & 1) * TW + (p % TW);
-    const int y = a.y0 + ty * BH + (wave >> 1) * TH + (p / TW);
-    const bool inTile = x < a.x1 && y < a.y1;
     const uint32_t spp = a.sampleCount;
+    const bool listMode = a.pixelList != nullptr;
+    const uint32_t listCount = listMode ? *a.pixelCount : 0u;
 
-    uint32_t stack[kStackDepth];
-    LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
-    uint32_t checksum = 0;
-    uint32_t primary[3] = { kNoHit, kNoHit, kNoHit };
-
-    float cr = 0.0f, cg = 0.0f, cb = 0.0f; // this lane's partial sum over its samples (:87-105)
-    if (inTile && z < spp) {
-        const uint32_t iters = (spp + 3u) / 4u; // BLOCK_DEPTH = 4 (GPURaytracer.hpp:19)
-        for (uint32_t iter = 0; iter < iters; iter++) {
-            const uint32_t sidx = iter * 4u + z;
-            if (sidx >= spp) break;
-            uint32_t seed = (uint32_t)x + (uint32_t)y * (uint32_t)a.width + sidx * 34673804u + a.frameCount * 719393u;
-
-            // setupRay (:140-163)
-            Ray ray;
-            ray.ox = a.camOrigin[0]; ray.oy = a.camOrigin[1]; ray.oz = a.camOrigin[2];
-            ray.maxDist = a.maxDistance;
-            V4 d;
-            if (a.antiAliasing) {
-                const float xf = (float)x + random_value(seed) - 0.5f;
-                const float yf = (float)y + random_value(seed) - 0.5f;
-                d = tex2d_rays(a.rays, a.width, a.height, xf, yf);
-            } else {
-                d = tex2d_rays(a.rays, a.width, a.height, (float)x, (float)y);
-            }
-            d = normalize4(rotate_q(d, a.camRotation));
-            ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
-
-            const V4 c = trace_path<MODE>(a, ray, seed, sidx, stack, st, checksum, primary);
-            // exposureCorrection (:690-698), per sample
-            cr += 1.0f - rtd::exp_f(-c.x * a.exposure);
-            cg += 1.0f - rtd::exp_f(-c.y * a.exposure);
-            cb += 1.0f - rtd::exp_f(-c.z * a.exposure);
-        }
-    }
-
-    // :107-116 -- lane z == 0 adds the partial sums of z = 0..3 in that order.  Lanes that the
-    // reference never writes (z >= spp) contribute 0.
-    float r = 0.0f, g = 0.0f, b = 0.0f;
-    uint32_t sum = 0;
-    const int base = lane & ~(L - 1);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        if (i < L) {
-            r += __shfl(cr, base + i);
-            g += __shfl(cg, base + i);
-            b += __shfl(cb, base + i);
-            sum += (uint32_t)__shfl((int)checksum, base + i);
+    for (uint32_t grp = blockIdx.x;; grp += gridDim.x) {
+        int x, y;
+        bool inTile;
+        if (listMode) {
+            if ((unsigned long long)grp * PIX_PER_WG >= listCount) break;
+            const uint32_t idx = grp * PIX_PER_WG + (uint32_t)(threadIdx.x >> LOG2L);
+            inTile = idx < listCount;
+            const uint32_t pix = inTile ? a.pixelList[idx] : 0u;
+            x = (int)(pix % (uint32_t)a.width); y = (int)(pix / (uint32_t)a.width);
         } else {
-            r += 0.0f; g += 0.0f; b += 0.0f;
+            const uint32_t nBlocks = (uint32_t)a.tilesX * (uint32_t)a.tilesY;
+            const uint32_t tile = xcd_remap(grp, nBlocks);
+            const int ty = (int)(tile / (uint32_t)a.tilesX), tx = (int)(tile % (uint32_t)a.tilesX);
+            x = a.x0 + tx * BW + (wave & 1) * TW + (p % TW);
+            y = a.y0 + ty * BH + (wave >> 1) * TH + (p / TW);
+            inTile = x < a.x1 && y < a.y1;
         }
-    }
 
-    if (inTile && z == 0) {
-        r /= (float)spp; g /= (float)spp; b /= (float)spp;
-        r = rtd::fmin_f(rtd::fmax_f(r, 0.0f), 1.0f); // :125-127
-        g = rtd::fmin_f(rtd::fmax_f(g, 0.0f), 1.0f);
-        b = rtd::fmin_f(rtd::fmax_f(b, 0.0f), 1.0f);
-        const size_t pix = (size_t)y * (size_t)a.width + (size_t)x;
-        if (a.progressiveFrameCount != 0) { // :129-134
-            const float4 prev = a.fb[pix];
-            const float n = (float)a.progressiveFrameCount, n1 = (float)(a.progressiveFrameCount + 1u);
-            r = (r + prev.x * n) / n1;
-            g = (g + prev.y * n) / n1;
-            b = (b + prev.z * n) / n1;
+        uint32_t checksum = 0;
+        uint32_t primary[3] = { kNoHit, kNoHit, kNoHit };
+        float cr = 0.0f, cg = 0.0f, cb = 0.0f; // this lane's partial sum over its samples (:87-105)
+        if (inTile && z < spp) {
+            const uint32_t iters = (spp + 3u) / 4u; // BLOCK_DEPTH = 4 (GPURaytracer.hpp:19)
+            for (uint32_t iter = 0; iter < iters; iter++) {
+                const uint32_t sidx = iter * 4u + z;
+                if (sidx >= spp) break;
+                uint32_t seed = sample_seed(a, x, y, sidx);
+                Ray ray = setup_ray(a, x, y, seed);
+                const V4 c = trace_path<MODE>(a, ray, seed, sidx, stack, st, checksum, primary);
+                // exposureCorrection (:690-698), per sample
+                cr += 1.0f - rtd::exp_f(-c.x * a.exposure);
+                cg += 1.0f - rtd::exp_f(-c.y * a.exposure);
+                cb += 1.0f - rtd::exp_f(-c.z * a.exposure);
+            }
         }
-        a.fb[pix] = make_float4(r, g, b, 1.0f);
-        if (a.ids) a.ids[pix] = make_uint4(primary[0], primary[1], primary[2], sum);
-    }
 
-    // counters: one atomic per wave and counter
-    unsigned long long v0 = st.rays, v1 = st.slow, v2 = st.bvh.nodes, v3 = st.bvh.tris + st.triBrute, v4 = st.hits;
+        // :107-116 -- lane z == 0 adds the partial sums of z = 0..3 in that order.  Lanes that the
+        // reference never writes (z >= spp) contribute 0.
+        float r = 0.0f, g = 0.0f, b = 0.0f;
+        uint32_t sum = 0;
+        const int base = lane & ~(L - 1);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        v0 += __shfl_xor(v0, off);
-        v1 += __shfl_xor(v1, off);
-        v2 += __shfl_xor(v2, off);
-        v3 += __shfl_xor(v3, off);
-        v4 += __shfl_xor(v4, off);
+        for (int i = 0; i < 4; i++) {
+            if (i < L) {
+                r += __shfl(cr, base + i);
+                g += __shfl(cg, base + i);
+                b += __shfl(cb, base + i);
+                sum += (uint32_t)__shfl((int)checksum, base + i);
+            } else {
+                r += 0.0f; g += 0.0f; b += 0.0f;
+            }
+        }
+        if (inTile && z == 0) write_pixel(a, x, y, r, g, b, primary, sum);
+        if (!listMode) break;
     }
-    if (lane == 0) {
-        atomicAdd(a.counters + 0, v0);
-        if (v1) atomicAdd(a.counters + 1, v1);
-        atomicAdd(a.counters + 2, v2);
-        atomicAdd(a.counters + 3, v3);
-        atomicAdd(a.counters + 4, v4);
-    }
+    flush_stats(a, st, wgCnt);
 }
 
 // closest-hit queries for caller-supplied rays (rt_trace_rays)
@@ -443,36 +666,53 @@ __global__ __launch_bounds__(256) void trace_rays_kernel(SceneView s, const floa
     if (i >= n) return;
     const float4 r0 = rays[2 * i], r1 = rays[2 * i + 1];
     Ray ray; ray.ox = r0.x; ray.oy = r0.y; ray.oz = r0.z; ray.maxDist = r0.w; ray.dx = r1.x; ray.dy = r1.y; ray.dz = r1.z;
-    uint32_t stack[kStackDepth];
+    __shared__ uint32_t ldsStack[kLdsStack * kBlock];
+    uint32_t ovf[kStackDepth - kLdsStack];
+    Stack stack; stack.lds = ldsStack + threadIdx.x; stack.ovf = ovf;
     LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
-    const Hit h = closest_hit<MODE>(s, ray, stack, st);
+    bool danger = false;
+    const Hit h = closest_hit<MODE>(s, ray, stack, st, danger);
     uint4 o = make_uint4(kNoHit, kNoHit, kNoHit, kNoHit);
     if (h.gid != kNoHit) {
         const TriShade* ts = s.triShade + h.gid;
         o = make_uint4(ts->obj, ts->mesh, ts->tri, __float_as_uint(h.t));
     }
     out[i] = o;
-    if (st.slow) atomicAdd(counters + 1, st.slow);
+    if (st.slow) atomicAdd(counters + 1, (unsigned long long)st.slow);
 }
 
-void launch_render(const RenderArgs& a, int mode, hipStream_t stream)
+// mode 0: persistent path kernel + redo launch for the pixels it flagged; mode 1: brute force
+void launch_render(const RenderArgs& a, int mode, int numCUs, hipStream_t stream)
 {
-    const uint32_t spp = a.sampleCount;
-    const int log2l = spp >= 3 ? 2 : (spp == 2 ? 1 : 0);
-    const int L = 1 << log2l;
-    const int BW = 2 * ((L == 4) ? 4 : 8), BH = 2 * ((L == 1) ? 8 : 4);
+    if (a.x1 <= a.x0 || a.y1 <= a.y0) return;
     RenderArgs b = a;
-    b.tilesX = (a.x1 - a.x0 + BW - 1) / BW;
-    b.tilesY = (a.y1 - a.y0 + BH - 1) / BH;
-    const uint32_t grid = (uint32_t)b.tilesX * (uint32_t)b.tilesY;
-    if (grid == 0) return;
-#define RT_LAUNCH(LG, MD) hipLaunchKernelGGL((render_kernel<LG, MD>), dim3(grid), dim3(256), 0, stream, b)
     if (mode == 1) {
-        if (log2l == 0) RT_LAUNCH(0, 1); else if (log2l == 1) RT_LAUNCH(1, 1); else RT_LAUNCH(2, 1);
-    } else {
-        if (log2l == 0) RT_LAUNCH(0, 0); else if (log2l == 1) RT_LAUNCH(1, 0); else RT_LAUNCH(2, 0);
+        const uint32_t spp = a.sampleCount;
+        const int log2l = spp >= 3 ? 2 : (spp == 2 ? 1 : 0);
+        const int L = 1 << log2l;
+        const int BW = 2 * ((L == 4) ? 4 : 8), BH = 2 * ((L == 1) ? 8 : 4);
+        b.tilesX = (a.x1 - a.x0 + BW - 1) / BW;
+        b.tilesY = (a.y1 - a.y0 + BH - 1) / BH;
+        b.pixelList = nullptr; b.pixelCount = nullptr;
+        const uint32_t grid = (uint32_t)b.tilesX * (uint32_t)b.tilesY;
+        if (log2l == 0) hipLaunchKernelGGL((render_kernel<0, 1>), dim3(grid), dim3(256), 0, stream, b);
+        else if (log2l == 1) hipLaunchKernelGGL((render_kernel<1, 1>), dim3(grid), dim3(256), 0, stream, b);
+        else hipLaunchKernelGGL((render_kernel<2, 1>), dim3(grid), dim3(256), 0, stream, b);
+        return;
     }
-#undef RT_LAUNCH
+    b.tiles8X = (a.x1 - a.x0 + 7) / 8;
+    b.tiles8Y = (a.y1 - a.y0 + 7) / 8;
+    const uint32_t nTiles = (uint32_t)b.tiles8X * (uint32_t)b.tiles8Y;
+    // persistent grid: 4 workgroups (16 waves) per CU is what 128 VGPRs admit; never more waves than tiles
+    uint32_t grid = (uint32_t)numCUs * 4u;
+    const uint32_t need = (nTiles + 3u) / 4u;
+    if (grid > need) grid = need;
+    if (grid < 8u) grid = 8u;
+    hipLaunchKernelGGL(path_kernel, dim3(grid), dim3(256), 0, stream, b);
+    // redo launch: exits at once when nothing was flagged
+    RenderArgs c = b;
+    c.pixelList = b.redoList; c.pixelCount = b.redoCount;
+    hipLaunchKernelGGL((render_kernel<2, 2>), dim3(256), dim3(256), 0, stream, c);
 }
 
 void launch_trace_rays(const SceneView& s, const float4* rays, int n, uint4* out, unsigned long long* counters, int mode,
@@ -481,7 +721,7 @@ void launch_trace_rays(const SceneView& s, const float4* rays, int n, uint4* out
     if (n <= 0) return;
     const int grid = (n + 255) / 256;
     if (mode == 1) hipLaunchKernelGGL((trace_rays_kernel<1>), dim3(grid), dim3(256), 0, stream, s, rays, n, out, counters);
-    else hipLaunchKernelGGL((trace_rays_kernel<0>), dim3(grid), dim3(256), 0, stream, s, rays, n, out, counters);
+    else hipLaunchKernelGGL((trace_rays_kernel<3>), dim3(grid), dim3(256), 0, stream, s, rays, n, out, counters);
 }
 
 } // namespace rt

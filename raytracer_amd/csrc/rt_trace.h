@@ -166,7 +166,7 @@ __device__ __forceinline__ ObjCull load_obj(const ObjCull* __restrict__ p)
 }
 
 // ------------------------------------------------------------------ brute force (reference order)
-__device__ __forceinline__ Hit trace_brute(const SceneView& s, Ray& ray, unsigned long long& triTests)
+__device__ __forceinline__ Hit trace_brute(const SceneView& s, Ray& ray, uint32_t& triTests)
 {
     Hit best; best.t = FLT_MAX; best.gid = kNoHit; best.b0 = best.b1 = best.b2 = 0.0f;
     const TriRay q = make_tri_ray(ray);
@@ -236,7 +236,27 @@ __device__ __forceinline__ bool box_test(const BoxRay& b, const float* __restric
     return tn <= tf;
 }
 
-struct BvhCounters { unsigned long long nodes, tris; };
+struct BvhCounters { uint32_t nodes, tris; };
+
+// Traversal stack: the first kLdsStack entries of every lane live in LDS, laid out
+// [entry][lane] so that lanes at the same depth hit distinct banks (ds latency ~64 cycles vs a
+// scratch round trip through L1/L2); deeper entries, rare, spill to a per-lane scratch array.
+struct Stack {
+    uint32_t* lds;   // already offset by the lane's slot
+    uint32_t* ovf;   // kStackDepth - kLdsStack entries of private memory
+    __device__ __forceinline__ void push(int& sp, uint32_t v) const
+    {
+        if (sp < kLdsStack) lds[sp * kBlock] = v;
+        else if (sp < kStackDepth) ovf[sp - kLdsStack] = v;
+        sp++;
+    }
+    __device__ __forceinline__ uint32_t pop(int& sp) const
+    {
+        --sp;
+        if (sp < kLdsStack) return lds[sp * kBlock];
+        return sp < kStackDepth ? ovf[sp - kLdsStack] : 0u;
+    }
+};
 
 // Band inside which a hit on a different object triggers the exact in-order emulation.
 __device__ __forceinline__ float band_of(float t, float rayScale) { return 2e-4f * (t + rayScale); }
@@ -244,7 +264,7 @@ __device__ __forceinline__ float band_of(float t, float rayScale) { return 2e-4f
 // Generic stack traversal.  `Visit` is called for every triangle of every reached leaf with its
 // leaf-order record; it returns the (possibly reduced) prune bound.
 template <class Visit>
-__device__ __forceinline__ void bvh_walk(const SceneView& s, const BoxRay& br, float bound, uint32_t* stack,
+__device__ __forceinline__ void bvh_walk(const SceneView& s, const BoxRay& br, float bound, const Stack& stack,
                                          BvhCounters& cnt, Visit&& visit)
 {
     if (!s.rootIsValid) return;
@@ -265,7 +285,7 @@ __device__ __forceinline__ void bvh_walk(const SceneView& s, const BoxRay& br, f
                 const bool leftFirst = tl <= tr;
                 const int32_t nearC = leftFirst ? left : right;
                 const int32_t farC = leftFirst ? right : left;
-                if (sp < kStackDepth) stack[sp++] = (uint32_t)farC;
+                stack.push(sp, (uint32_t)farC);
                 cur = nearC;
                 continue;
             } else if (hl) { cur = left; continue; }
@@ -281,7 +301,7 @@ __device__ __forceinline__ void bvh_walk(const SceneView& s, const BoxRay& br, f
             }
         }
         if (sp == 0) break;
-        cur = (int32_t)stack[--sp];
+        cur = (int32_t)stack.pop(sp);
     }
 }
 
@@ -302,7 +322,7 @@ __device__ __forceinline__ void cull_lookup(const SceneView& s, const Ray& ray, 
 // Exact emulation of :247-265 restricted to the objects that have an accepted hit with
 // t <= limit (objects beyond cannot change the outcome).
 __device__ __noinline__ Hit trace_bvh_exact(const SceneView& s, Ray& ray, const TriRay& q, const BoxRay& br,
-                                            float limit, uint32_t* stack, BvhCounters& cnt)
+                                            float limit, const Stack& stack, BvhCounters& cnt)
 {
     Hit best; best.t = FLT_MAX; best.gid = kNoHit; best.b0 = best.b1 = best.b2 = 0.0f;
     const float m0 = ray.maxDist;
@@ -339,7 +359,7 @@ __device__ __noinline__ Hit trace_bvh_exact(const SceneView& s, Ray& ray, const 
                     }
                 }
             }
-            return bound;
+            return __builtin_fminf(bound, ob.t);
         });
         if (ob.gid != kNoHit && ob.t < best.t) {
             best = ob;
@@ -350,8 +370,12 @@ __device__ __noinline__ Hit trace_bvh_exact(const SceneView& s, Ray& ray, const 
     return best;
 }
 
-__device__ __forceinline__ Hit trace_bvh(const SceneView& s, Ray& ray, uint32_t* stack, BvhCounters& cnt,
-                                         unsigned long long& slowPath)
+// EXACT = true: rays inside the band take trace_bvh_exact inline (rt_trace_rays, small kernels).
+// EXACT = false: the hot render kernel only reports `danger`; the pixel is re-rendered by the
+// redo launch, which keeps the rare path (and its registers) out of the hot kernel.
+template <bool EXACT>
+__device__ __forceinline__ Hit trace_bvh(const SceneView& s, Ray& ray, const Stack& stack, BvhCounters& cnt,
+                                         uint32_t& slowPath, bool& danger)
 {
     Hit best; best.t = FLT_MAX; best.gid = kNoHit; best.b0 = best.b1 = best.b2 = 0.0f;
     if (!s.rootIsValid) return best;
@@ -387,10 +411,22 @@ __device__ __forceinline__ Hit trace_bvh(const SceneView& s, Ray& ray, uint32_t*
     const float limit = best.t + band_of(best.t, rayScale);
     if (otherT <= limit) {
         slowPath++;
-        return trace_bvh_exact(s, ray, q, br, __builtin_fminf(limit, m0), stack, cnt);
+        if (EXACT) return trace_bvh_exact(s, ray, q, br, __builtin_fminf(limit, m0), stack, cnt);
+        danger = true;
     }
     ray.maxDist = best.t;
     return best;
+}
+
+// the reference loop itself with the BVH used for culling only: every object with an accepted hit,
+// in index order (redo launch)
+__device__ __forceinline__ Hit trace_bvh_exact_all(const SceneView& s, Ray& ray, const Stack& stack, BvhCounters& cnt)
+{
+    Hit none; none.t = FLT_MAX; none.gid = kNoHit; none.b0 = none.b1 = none.b2 = 0.0f;
+    if (!s.rootIsValid) return none;
+    const TriRay q = make_tri_ray(ray);
+    const BoxRay br = make_box_ray(ray, s.sceneMaxAbs);
+    return trace_bvh_exact(s, ray, q, br, ray.maxDist, stack, cnt);
 }
 
 } // namespace rt
