@@ -85,7 +85,11 @@ def main():
     flat = scene.flatten()
 
     ctx = capi.Context(local_rank)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    # a real (non-null) stream shared by torch and librt_amd: rt_set_stream(NULL) would mean the
+    # context's own stream, and the legacy default stream's handle IS null
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ctx.set_stream(stream.cuda_stream)
     ctx.set_option(capi.OPT_TRAVERSAL, 1 if args.brute else 0)
     t0 = time.time()
     ctx.upload_scene(flat)

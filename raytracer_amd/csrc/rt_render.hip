@@ -242,15 +242,14 @@ struct LaneStats {
 
 // MODE 0: BVH, rays inside the tie band only raise `danger` (hot kernel)
 // MODE 1: brute force in reference order
-// MODE 2: the reference loop with the BVH as a culling device only (redo launch)
-// MODE 3: BVH with the exact path inline (rt_trace_rays)
+// MODE 2 / 3: BVH with the exact in-order emulation inline for rays inside the tie band
+//             (redo launch / rt_trace_rays)
 template <int MODE>
 __device__ __forceinline__ Hit closest_hit(const SceneView& s, Ray& ray, const Stack& stack, LaneStats& st, bool& danger)
 {
     st.rays++;
     if (MODE == 1) return trace_brute(s, ray, st.triBrute);
-    if (MODE == 2) return trace_bvh_exact_all(s, ray, stack, st.bvh);
-    if (MODE == 3) return trace_bvh<true>(s, ray, stack, st.bvh, st.slow, danger);
+    if (MODE == 2 || MODE == 3) return trace_bvh<true>(s, ray, stack, st.bvh, st.slow, danger);
     return trace_bvh<false>(s, ray, stack, st.bvh, st.slow, danger);
 }
 

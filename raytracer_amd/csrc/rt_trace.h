@@ -263,16 +263,22 @@ __device__ __forceinline__ float band_of(float t, float rayScale) { return 2e-4f
 
 // Generic stack traversal.  `Visit` is called for every triangle of every reached leaf with its
 // leaf-order record; it returns the (possibly reduced) prune bound.
+// "while-while" traversal (Aila & Laine 2009): a lane that reaches a leaf parks it and keeps
+// descending until every lane of the wave still searching has a leaf too; then the wave runs the
+// triangle tests together.  Node visits and triangle tests no longer serialise against each other
+// inside a wave (VALU lane utilisation of the first kernel was 32 %).
 template <class Visit>
 __device__ __forceinline__ void bvh_walk(const SceneView& s, const BoxRay& br, float bound, const Stack& stack,
                                          BvhCounters& cnt, Visit&& visit)
 {
     if (!s.rootIsValid) return;
+    constexpr int32_t kEnd = 0x7FFFFFFF; // traversal finished / no leaf parked (internal nodes are < kEnd, leaves < 0)
     int sp = 0;
-    int32_t cur = 0; // root
-    for (;;) {
-        if (cur >= 0) {
-            const float4* np = reinterpret_cast<const float4*>(s.nodes + cur);
+    int32_t node = 0; // root
+    int32_t leaf = kEnd;
+    while (node != kEnd) {
+        while (node >= 0 && node != kEnd) {
+            const float4* np = reinterpret_cast<const float4*>(s.nodes + node);
             const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
             cnt.nodes++;
             const float lmin[3] = { n0.x, n0.y, n0.z }, lmax[3] = { n0.w, n1.x, n1.y };
@@ -283,15 +289,19 @@ __device__ __forceinline__ void bvh_walk(const SceneView& s, const BoxRay& br, f
             const bool hr = box_test(br, rmin, rmax, bound, tr);
             if (hl && hr) {
                 const bool leftFirst = tl <= tr;
-                const int32_t nearC = leftFirst ? left : right;
-                const int32_t farC = leftFirst ? right : left;
-                stack.push(sp, (uint32_t)farC);
-                cur = nearC;
-                continue;
-            } else if (hl) { cur = left; continue; }
-            else if (hr) { cur = right; continue; }
-        } else {
-            const uint32_t code = (uint32_t)(~cur);
+                stack.push(sp, (uint32_t)(leftFirst ? right : left));
+                node = leftFirst ? left : right;
+            } else if (hl) node = left;
+            else if (hr) node = right;
+            else node = sp > 0 ? (int32_t)stack.pop(sp) : kEnd;
+            if (node < 0 && leaf == kEnd) { // park the first leaf, keep searching
+                leaf = node;
+                node = sp > 0 ? (int32_t)stack.pop(sp) : kEnd;
+            }
+            if (!__any(leaf == kEnd)) break; // every searching lane holds a leaf
+        }
+        while (leaf != kEnd) {
+            const uint32_t code = (uint32_t)(~leaf);
             const uint32_t first = code >> 3, count = (code & 7u) + 1u;
             for (uint32_t k = 0; k < count; k++) {
                 const float4* p = reinterpret_cast<const float4*>(s.triLeaf + first + k);
@@ -299,9 +309,12 @@ __device__ __forceinline__ void bvh_walk(const SceneView& s, const BoxRay& br, f
                 cnt.tris++;
                 bound = visit(A, B, C, bound);
             }
+            leaf = kEnd;
+            if (node < 0) { // a second leaf was reached while the first was parked
+                leaf = node;
+                node = sp > 0 ? (int32_t)stack.pop(sp) : kEnd;
+            }
         }
-        if (sp == 0) break;
-        cur = (int32_t)stack.pop(sp);
     }
 }
 
