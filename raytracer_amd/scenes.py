@@ -154,3 +154,147 @@ def config2(width=1920, height=1080, spp=16, depth=4, tex_size=1024):
     cam.setWidth(width); cam.setHeight(height); cam.calcRays()
     st = RenderSettings(bounceCount=depth, sampleCount=spp)
     return scene, cam, st
+
+
+def _quat_axis_angle(axis, deg):
+    a = np.asarray(axis, np.float64); a = a / np.linalg.norm(a)
+    h = np.radians(deg) / 2
+    return tuple(np.float32(v) for v in (*(a * np.sin(h)), np.cos(h)))
+
+
+def _look_quat(pitch_deg, yaw_deg=0.0):
+    """Camera quaternion: yaw about +y, then pitch about the camera's x axis."""
+    qy = np.array(_quat_axis_angle((0, 1, 0), yaw_deg), np.float64)
+    qx = np.array(_quat_axis_angle((1, 0, 0), pitch_deg), np.float64)
+    x1, y1, z1, w1 = qy; x2, y2, z2, w2 = qx
+    q = (w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+         w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2)
+    return tuple(np.float32(v) for v in q)
+
+
+def sword_mesh():
+    """Stand-in for res/pbrsword/source/murasama.fbx (4 671 control points, ~8 972 triangles after
+    fan triangulation; the FBX cannot travel to the GPU box): a katana-like blade, guard and
+    wrapped handle with about the same triangle count and extents (x in [-2.5, 2.5])."""
+    parts = [
+        ellipsoid_mesh(1.9, 0.17, 0.035, 96, 24, (0.6, 0.0, 0.0)),     # blade   4416
+        ellipsoid_mesh(0.06, 0.26, 0.2, 32, 12, (-1.3, 0.0, 0.0)),     # guard    704
+        ellipsoid_mesh(0.62, 0.09, 0.07, 64, 16, (-1.9, 0.0, 0.0)),    # handle  1920
+        ellipsoid_mesh(0.1, 0.11, 0.09, 32, 16, (-2.45, 0.0, 0.0)),    # pommel   960
+        ellipsoid_mesh(0.3, 0.06, 0.05, 32, 16, (-1.75, 0.0, 0.08)),   # ornament 960
+    ]
+    return merge_meshes(parts)
+
+
+def config3(width=3840, height=2160, spp=64, depth=4, tex_size=2048):
+    """C3 (BASELINE.json configs[2]): PBR sword stand-in with albedo / normal / roughness / metal 2048^2
+    textures, 3840x2160, 64 spp.  Geometry and textures are synthetic (the FBX and its textures are
+    reference assets that do not travel; the real normal map is a missing blob anyway)."""
+    width, height, spp, depth = width or 3840, height or 2160, spp or 64, depth or 4
+    scene = Scene()
+    steel = Material("Steel", (0.8, 0.8, 0.85, 1.0), 0.3, 1.0)
+    steel.setAlbedoTexture(Texture(procedural_texture(tex_size, 11, "albedo")))
+    steel.setNormalTexture(Texture(procedural_texture(tex_size, 12, "normal")))
+    steel.setRoughnessTexture(Texture(procedural_texture(tex_size, 13, "scalar")[..., 0]))
+    steel.setMetalTexture(Texture(procedural_texture(tex_size, 14, "scalar")[..., 0]))
+    stone = Material("Stone", (0.5, 0.48, 0.45, 1.0), 0.8, 0.0)
+    sword = MeshObject([(sword_mesh(), 0)], [steel], position=(0.0, 0.45, 0.0), rotation=_quat_axis_angle((0, 0, 1), 12.0))
+    plinth = MeshObject([(merge_meshes([box_mesh((-3.2, -0.3, -1.2), (3.2, 0.0, 1.2))]), 0)], [stone])
+    scene.addToScene("sword", sword)
+    scene.addToScene("plinth", plinth)
+    cam = Camera((0.0, 1.4, 5.2), _look_quat(-12.0), 45.0, 1.0)
+    cam.setWidth(width); cam.setHeight(height); cam.calcRays()
+    return scene, cam, RenderSettings(bounceCount=depth, sampleCount=spp)
+
+
+def trashcan_meshes():
+    """Stand-in for res/lowpolypbrtrash/source/model.dae: 6 meshes with the DAE's triangle counts
+    (640 + 896 + 4 x 372 = 3 024)."""
+    body = merge_meshes([ellipsoid_mesh(0.45, 0.6, 0.45, 32, 11, (0, 0.6, 0))])        # 640
+    lid = merge_meshes([ellipsoid_mesh(0.5, 0.12, 0.5, 32, 15, (0, 1.25, 0))])          # 896
+    wheels = [merge_meshes([ellipsoid_mesh(0.12, 0.12, 0.06, 31, 7, (sx * 0.35, 0.12, sz * 0.42))])
+              for sx in (-1, 1) for sz in (-1, 1)]                                        # 4 x 372
+    return [body, lid] + wheels
+
+
+def config4(width=3840, height=2160, spp=4, depth=4, tex_size=2048, instances=331):
+    """C4 (BASELINE.json configs[3]): 331 instances of a 3 024-triangle, 6-mesh model = 1 000 944
+    triangles on a jittered grid (LCG seed 1), two PBR material sets with four textures each, 4K.
+    Synthetic stand-in for lowpolypbrtrash + metalmaterial (reference assets do not travel)."""
+    width, height, spp, depth = width or 3840, height or 2160, spp or 4, depth or 4
+    scene = Scene()
+    mats = []
+    for k, (rough, metal) in enumerate(((0.7, 0.0), (0.25, 1.0))):
+        m = Material(f"Set{k}", (0.8, 0.8, 0.8, 1.0), rough, metal)
+        m.setAlbedoTexture(Texture(procedural_texture(tex_size, 21 + 10 * k, "albedo")))
+        m.setNormalTexture(Texture(procedural_texture(tex_size, 22 + 10 * k, "normal")))
+        m.setRoughnessTexture(Texture(procedural_texture(tex_size // 2, 23 + 10 * k, "scalar")[..., 0]))
+        m.setMetalTexture(Texture(procedural_texture(tex_size // 2, 24 + 10 * k, "scalar")[..., 0]))
+        mats.append(m)
+    ground = Material("Floor", (0.4, 0.4, 0.42, 1.0), 0.9, 0.0)
+    meshes = trashcan_meshes()
+    side = int(np.ceil(np.sqrt(instances)))
+    state = 1
+    def lcg():
+        nonlocal state
+        state = (state * 1664525 + 1013904223) & 0xFFFFFFFF
+        return state / 4294967296.0
+    for i in range(instances):
+        gx, gz = i % side, i // side
+        pos = ((gx - side / 2) * 1.6 + (lcg() - 0.5) * 0.5, 0.0, (gz - side / 2) * 1.6 + (lcg() - 0.5) * 0.5)
+        rot = _quat_axis_angle((0, 1, 0), lcg() * 360.0)
+        s = 0.85 + 0.3 * lcg()
+        k = i % 2
+        o = MeshObject([(m, 0 if j < 2 else 1) for j, m in enumerate(meshes)], [mats[k], mats[1 - k]], pos, rot, (s, s, s))
+        scene.addToScene(f"can{i}", o)
+    ext = side * 0.8 + 2
+    scene.addToScene("floor", MeshObject([(merge_meshes([box_mesh((-ext, -0.25, -ext), (ext, 0.0, ext))]), 0)], [ground]))
+    cam = Camera((0.0, 9.0, side * 0.8 + 9.0), _look_quat(-28.0), 45.0, 1.0)
+    cam.setWidth(width); cam.setHeight(height); cam.calcRays()
+    return scene, cam, RenderSettings(bounceCount=depth, sampleCount=spp)
+
+
+def terrain_mesh(n=2236, size=400.0, seed=2):
+    """Height-field grid: 2*n*n triangles (n = 2236 -> 9 999 392)."""
+    rng = np.random.default_rng(seed)
+    g = np.linspace(-size / 2, size / 2, n + 1, dtype=np.float32)
+    X, Z = np.meshgrid(g, g, indexing="xy")
+    Y = np.zeros_like(X)
+    for k in range(1, 7):
+        fx, fz, ph = rng.uniform(0.01, 0.12) * k, rng.uniform(0.01, 0.12) * k, rng.uniform(0, 6.28, 2)
+        Y += (3.0 / k) * np.sin(fx * X + ph[0]) * np.cos(fz * Z + ph[1])
+    Y = Y.astype(np.float32)
+    v = np.stack([X, Y, Z], -1).reshape(-1, 3)
+    dy_dx = np.gradient(Y, g, axis=1); dy_dz = np.gradient(Y, g, axis=0)
+    nr = np.stack([-dy_dx, np.ones_like(Y), -dy_dz], -1).astype(np.float32)
+    nr /= np.linalg.norm(nr, axis=-1, keepdims=True)
+    uv = np.stack([(X / size + 0.5) * 8 % 1.0, (Z / size + 0.5) * 8 % 1.0], -1).astype(np.float32).reshape(-1, 2)
+    i = (np.arange(n)[:, None] * (n + 1) + np.arange(n)[None, :]).reshape(-1).astype(np.int32)
+    idx = np.stack([i, i + n + 2, i + 1, i, i + n + 1, i + n + 2], -1).reshape(-1)
+    return Mesh(v.reshape(-1), idx, uv.reshape(-1), nr.reshape(-1, 3).reshape(-1))
+
+
+def config5(width=7680, height=4320, spp=1, depth=4, spheres=10000, grid=2236):
+    """C5 (BASELINE.json configs[4]): ~10 M-triangle terrain + 10 000 tessellated spheres (352 triangles
+    each, seed 2), 7680x4320; 256 spp are accumulated as progressive frames split over the GPUs."""
+    width, height, spp, depth = width or 7680, height or 4320, spp or 1, depth or 4
+    scene = Scene()
+    rock = Material("Rock", (0.55, 0.5, 0.45, 1.0), 0.85, 0.0)
+    rock.setAlbedoTexture(Texture(procedural_texture(2048, 41, "albedo")))
+    shiny = [Material(f"Ball{k}", tuple(c) + (1.0,), r, m) for k, (c, r, m) in enumerate(
+        (((0.9, 0.3, 0.3), 0.3, 0.0), ((0.9, 0.9, 0.95), 0.1, 1.0), ((0.3, 0.6, 0.9), 0.6, 0.0), ((1.0, 0.8, 0.4), 0.2, 1.0)))]
+    shiny[0].emissionStrength = np.float32(0.0)
+    tm = terrain_mesh(grid)
+    scene.addToScene("terrain", MeshObject([(tm, 0)], [rock]))
+    rng = np.random.default_rng(2)
+    Y = tm.vertices.reshape(grid + 1, grid + 1, 3)
+    for i in range(spheres):
+        gx, gz = rng.integers(0, grid + 1, 2)
+        p = Y[gz, gx]
+        r = float(rng.uniform(0.4, 1.5))
+        s = Sphere(position=(float(p[0]), float(p[1]) + r * 0.45, float(p[2])), scale=(r, r, r))
+        s.setMaterial(shiny[i % 4])
+        scene.addToScene(f"s{i}", s)
+    cam = Camera((0.0, 60.0, 230.0), _look_quat(-18.0), 45.0, 1.0)
+    cam.setWidth(width); cam.setHeight(height); cam.calcRays()
+    return scene, cam, RenderSettings(bounceCount=depth, sampleCount=spp, maxDistance=1000.0)

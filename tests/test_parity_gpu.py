@@ -349,3 +349,30 @@ def test_full_size_properties(ctx):
     assert np.array_equal(ref[y0:y0 + 64, x0:x0 + 64], a[y0:y0 + 64, x0:x0 + 64])
     assert np.array_equal(rid[y0:y0 + 64, x0:x0 + 64], ia[y0:y0 + 64, x0:x0 + 64])
     ctx.framebuffer_destroy(fb); ctx.framebuffer_destroy(fb2)
+
+
+@pytest.mark.parametrize("name,args,rect", [
+    ("config3", (256, 144, 4, 4, 128), None),
+    ("config4", (256, 144, 2, 4, 64), None),
+    ("config4", (3840, 2160, 1, 4, 64), (1900, 700, 1964, 764)),     # full 4K frame, oracle on a 64x64 crop
+    ("config5", (256, 144, 1, 4, 300, 120), None),                   # reduced: 28 800-triangle terrain + 300 spheres
+])
+def test_larger_configs_against_oracle(ctx, name, args, rect):
+    scene, cam, st = getattr(scenes, name)(*args)
+    flat = scene.flatten()
+    ref, rid, nq = orc.render(flat, cam, st, rect=rect)
+    ctx.set_option(capi.OPT_TRAVERSAL, 0)
+    ctx.upload_scene(flat)
+    ctx.set_camera_rays(cam.preTransformRays)
+    fb = ctx.framebuffer(cam.width, cam.height, ids=True)
+    ctx.render(cam, st, fb)
+    img, ids, stats = ctx.read(fb, cam.width, cam.height), ctx.read_ids(fb, cam.width, cam.height), ctx.stats()
+    ctx.framebuffer_destroy(fb)
+    if rect is None:
+        check(ref, rid, nq, img, ids, stats)
+        assert np.array_equal(img, ref, equal_nan=True)
+    else:
+        x0, y0, x1, y1 = rect
+        assert np.array_equal(ids[y0:y1, x0:x1], rid[y0:y1, x0:x1])
+        assert np.array_equal(img[y0:y1, x0:x1], ref[y0:y1, x0:x1], equal_nan=True)
+        assert (rid[y0:y1, x0:x1, 0] != 0xFFFFFFFF).any()
