@@ -83,6 +83,8 @@ typedef struct {
     uint64_t node_visits;  /* BVH node visits of the last rt_render */
     uint64_t tri_tests;    /* triangle tests of the last rt_render */
     uint64_t hits;         /* closest-hit queries that hit and were shaded */
+    uint64_t idle_node_lanes; /* diagnostic builds (-DRT_UTIL_COUNTERS): idle lane slots in the node loop */
+    uint64_t idle_tri_lanes;  /* ... and in the triangle loop; 0 in the shipped library */
 } rt_stats;
 
 enum rt_option {

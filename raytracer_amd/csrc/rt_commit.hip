@@ -3,9 +3,9 @@
 //
 // Replaces the per-frame instance table of Scene::getGPUObjectDataVector (Scene.cpp:3-29) and the
 // pointer tables of DisplayObject::sendToGPU (DisplayObject.cpp:30-81).  The reference builds no
-// acceleration structure; this file adds one (LBVH: Morton codes -> radix sort -> Karras radix
-// tree -> level-synchronous box fit -> 64-byte two-child nodes with up to kLeafMax triangles per
-// leaf).  World-space positions and normals are produced with the reference's own expressions
+// acceleration structure; this file adds one (LBVH: 63-bit Morton codes -> radix sort -> Karras
+// radix tree -> level-synchronous box fit -> top-down collapse into 128-byte four-wide nodes with up
+// to kLeafMax triangles per leaf).  World-space positions and normals are produced with the reference's own expressions
 // (matVecMul, GPURaytracer.cu:728-743; normals through the transposed inverse, :463-469) so the
 // render kernel tests exactly the triangles the reference would.
 #include "rt_device.h"
@@ -128,13 +128,16 @@ __global__ __launch_bounds__(256) void flatten_kernel(const Segment* __restrict_
     }
 }
 
-__device__ __forceinline__ uint32_t expand_bits10(uint32_t v)
+// spreads the low 21 bits of v so that two zero bits follow each of them
+__device__ __forceinline__ unsigned long long expand_bits21(uint32_t v)
 {
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
-    return v;
+    unsigned long long x = v & 0x1FFFFFull;
+    x = (x | (x << 32)) & 0x001F00000000FFFFull;
+    x = (x | (x << 16)) & 0x001F0000FF0000FFull;
+    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
 }
 
 __device__ __forceinline__ void tri_box(const TriIsect& t, float* mn, float* mx)
@@ -145,8 +148,8 @@ __device__ __forceinline__ void tri_box(const TriIsect& t, float* mn, float* mx)
 }
 
 __global__ __launch_bounds__(256) void morton_kernel(const TriIsect* __restrict__ triRef, uint32_t nTris,
-                                                     const uint32_t* __restrict__ bounds, uint32_t* __restrict__ keys,
-                                                     uint32_t* __restrict__ vals)
+                                                     const uint32_t* __restrict__ bounds,
+                                                     unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nTris) return;
@@ -156,10 +159,12 @@ __global__ __launch_bounds__(256) void morton_kernel(const TriIsect* __restrict_
     tri_box(triRef[g], mn, mx);
     const float cx = 0.5f * (mn[0] + mx[0]), cy = 0.5f * (mn[1] + mx[1]), cz = 0.5f * (mn[2] + mx[2]);
     float fx = ex > 0.0f ? (cx - bx) / ex : 0.0f, fy = ey > 0.0f ? (cy - by) / ey : 0.0f, fz = ez > 0.0f ? (cz - bz) / ez : 0.0f;
-    fx = __builtin_fminf(__builtin_fmaxf(fx * 1024.0f, 0.0f), 1023.0f); // NaN -> 0
-    fy = __builtin_fminf(__builtin_fmaxf(fy * 1024.0f, 0.0f), 1023.0f);
-    fz = __builtin_fminf(__builtin_fmaxf(fz * 1024.0f, 0.0f), 1023.0f);
-    keys[g] = (expand_bits10((uint32_t)fx) << 2) | (expand_bits10((uint32_t)fy) << 1) | expand_bits10((uint32_t)fz);
+    // 21 bits per axis: with 10 the small triangles of a detailed object inside a large scene share
+    // one cell and the bottom of the tree degenerates into index-order splits
+    fx = __builtin_fminf(__builtin_fmaxf(fx * 2097152.0f, 0.0f), 2097151.0f); // NaN -> 0
+    fy = __builtin_fminf(__builtin_fmaxf(fy * 2097152.0f, 0.0f), 2097151.0f);
+    fz = __builtin_fminf(__builtin_fmaxf(fz * 2097152.0f, 0.0f), 2097151.0f);
+    keys[g] = (expand_bits21((uint32_t)fx) << 2) | (expand_bits21((uint32_t)fy) << 1) | expand_bits21((uint32_t)fz);
     vals[g] = g;
 }
 
@@ -180,15 +185,15 @@ __global__ __launch_bounds__(256) void gather_kernel(const TriIsect* __restrict_
 
 // Karras 2012, "Maximizing parallelism in the construction of BVHs, octrees and k-d trees":
 // internal node i of the binary radix tree over the sorted keys (ties broken by position).
-__device__ __forceinline__ int delta(const uint32_t* __restrict__ keys, int n, int i, int j)
+__device__ __forceinline__ int delta(const unsigned long long* __restrict__ keys, int n, int i, int j)
 {
     if (j < 0 || j >= n) return -1;
-    const uint32_t a = keys[i], b = keys[j];
-    if (a == b) return 32 + __clz((uint32_t)(i ^ j));
-    return __clz(a ^ b);
+    const unsigned long long a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz((uint32_t)(i ^ j));
+    return __clzll((long long)(a ^ b));
 }
 
-__global__ __launch_bounds__(256) void karras_kernel(const uint32_t* __restrict__ keys, int n, int2* __restrict__ children,
+__global__ __launch_bounds__(256) void karras_kernel(const unsigned long long* __restrict__ keys, int n, int2* __restrict__ children,
                                                      int2* __restrict__ ranges)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -238,43 +243,161 @@ __global__ __launch_bounds__(256) void fit_kernel(const int2* __restrict__ child
     done[i] = pass;
 }
 
-__device__ __forceinline__ int32_t encode_child(int c, const int2* __restrict__ ranges)
+// ---- collapse of the binary tree into four-wide nodes, top down, one launch per level ----
+// A task = (binary internal node, index of the four-wide node to write).  The node's children are
+// the binary node's two children, with the larger (by surface area) internal ones replaced by
+// their own children until four slots are used.  A binary subtree of at most kLeafMax triangles
+// becomes a leaf (its triangles are contiguous in leaf order).
+__device__ __forceinline__ bool is_leaf_subtree(int c, const int2* __restrict__ ranges)
 {
-    if (c < 0) return ~(int32_t)(((uint32_t)(~c) << 3) | 0u);
+    if (c < 0) return true;
     const int2 r = ranges[c];
-    const int count = r.y - r.x + 1;
-    if (count <= kLeafMax) return ~(int32_t)(((uint32_t)r.x << 3) | (uint32_t)(count - 1));
-    return c;
+    return r.y - r.x + 1 <= kLeafMax;
 }
 
-__global__ __launch_bounds__(256) void emit_kernel(const int2* __restrict__ children, const int2* __restrict__ ranges,
-                                                   const float* __restrict__ boxes, int nInternal, int nLeaves,
-                                                   BvhNode* __restrict__ nodes)
+__device__ __forceinline__ const float* box_of(int c, const float* __restrict__ boxes, int nLeaves)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nInternal) return;
-    const int2 c = children[i];
-    const float* a = boxes + 6 * (size_t)(c.x < 0 ? nLeaves - 1 + (~c.x) : c.x);
-    const float* b = boxes + 6 * (size_t)(c.y < 0 ? nLeaves - 1 + (~c.y) : c.y);
-    BvhNode nd;
-    nd.lmin[0] = a[0]; nd.lmin[1] = a[1]; nd.lmin[2] = a[2]; nd.lmax[0] = a[3]; nd.lmax[1] = a[4]; nd.lmax[2] = a[5];
-    nd.rmin[0] = b[0]; nd.rmin[1] = b[1]; nd.rmin[2] = b[2]; nd.rmax[0] = b[3]; nd.rmax[1] = b[4]; nd.rmax[2] = b[5];
-    nd.left = encode_child(c.x, ranges);
-    nd.right = encode_child(c.y, ranges);
-    nd.pad[0] = nd.pad[1] = 0;
-    nodes[i] = nd;
+    return boxes + 6 * (size_t)(c < 0 ? nLeaves - 1 + (~c) : c);
 }
 
-// single-triangle scene: one node, the second child is an empty box
+__global__ __launch_bounds__(256) void collapse_kernel(const int2* __restrict__ children, const int2* __restrict__ ranges,
+                                                       const float* __restrict__ boxes, int nLeaves,
+                                                       const int2* __restrict__ qIn, uint32_t qCount,
+                                                       int2* __restrict__ qOut, uint32_t* __restrict__ qOutCount,
+                                                       uint32_t* __restrict__ nodeCount, BvhNode* __restrict__ nodes)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= qCount) return;
+    const int2 task = qIn[i];
+    int c0, c1, c2 = 0, c3 = 0, n = 2;
+    { const int2 c = children[task.x]; c0 = c.x; c1 = c.y; }
+    for (int iter = 0; iter < 2; iter++) {
+        int bestK = -1; float bestA = -1.0f;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (k >= n) break;
+            const int c = k == 0 ? c0 : (k == 1 ? c1 : (k == 2 ? c2 : c3));
+            if (is_leaf_subtree(c, ranges)) continue;
+            const float* b = boxes + 6 * (size_t)c;
+            const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+            float A = dx * dy + dy * dz + dz * dx;
+            if (!(A >= 0.0f)) A = 0.0f; // NaN boxes (non-finite vertices) still get expanded
+            if (A > bestA) { bestA = A; bestK = k; }
+        }
+        if (bestK < 0) break;
+        const int e = bestK == 0 ? c0 : (bestK == 1 ? c1 : (bestK == 2 ? c2 : c3));
+        const int2 cc = children[e];
+        // replace slot bestK by the two children, keeping the left-to-right order of the binary tree
+        if (bestK == 0) { c3 = c2; c2 = c1; c0 = cc.x; c1 = cc.y; }
+        else if (bestK == 1) { c3 = c2; c1 = cc.x; c2 = cc.y; }
+        else { c2 = cc.x; c3 = cc.y; }
+        n++;
+    }
+    const int cs[4] = { c0, c1, c2, c3 };
+    int m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (k < n && !is_leaf_subtree(cs[k], ranges)) m++;
+    uint32_t base = 0, qbase = 0;
+    if (m > 0) { base = atomicAdd(nodeCount, (uint32_t)m); qbase = atomicAdd(qOutCount, (uint32_t)m); }
+    // node box = union of the child boxes, clamped so that the extents stay finite
+    const float kBig = 1e30f;
+    float lo[4][3], hi[4][3];
+    float nlo[3] = { kBig, kBig, kBig }, nhi[3] = { -kBig, -kBig, -kBig };
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (k >= n) break;
+        const float* b = box_of(cs[k], boxes, nLeaves);
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            lo[k][a] = __builtin_fminf(__builtin_fmaxf(b[a], -kBig), kBig);       // NaN -> -kBig / +kBig: covers everything
+            hi[k][a] = __builtin_fmaxf(__builtin_fminf(b[3 + a], kBig), -kBig);
+            nlo[a] = __builtin_fminf(nlo[a], lo[k][a]);
+            nhi[a] = __builtin_fmaxf(nhi[a], hi[k][a]);
+        }
+    }
+    BvhNode nd;
+    nd.ox = nlo[0]; nd.oy = nlo[1]; nd.oz = nlo[2];
+    float sc[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        // smallest power of two with extent / scale <= 250 (five steps of slack for the outward rounding below)
+        const float ext = nhi[a] - nlo[a];
+        int e;
+        const float m = frexpf(ext * (1.0f / 250.0f), &e);   // ext/250 = m * 2^e, m in [0.5, 1)
+        e = (ext > 0.0f) ? (m == 0.5f ? e - 1 : e) : -120;
+        if (e < -120) e = -120;
+        sc[a] = ldexpf(1.0f, e);
+    }
+    nd.sx = sc[0]; nd.sy = sc[1]; nd.sz = sc[2];
+    uint32_t ql[3] = { 0, 0, 0 }, qh[3] = { 0, 0, 0 };
+    int j = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (k < n) {
+            const int c = cs[k];
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                int q0 = (int)floorf((lo[k][a] - nlo[a]) / sc[a]);
+                q0 = q0 < 0 ? 0 : (q0 > 255 ? 255 : q0);
+                while (q0 > 0 && nlo[a] + (float)q0 * sc[a] > lo[k][a]) q0--;
+                int q1 = (int)ceilf((hi[k][a] - nlo[a]) / sc[a]);
+                q1 = q1 < 0 ? 0 : (q1 > 255 ? 255 : q1);
+                while (q1 < 255 && nlo[a] + (float)q1 * sc[a] < hi[k][a]) q1++;
+                ql[a] |= (uint32_t)q0 << (8 * k);
+                qh[a] |= (uint32_t)q1 << (8 * k);
+            }
+            if (c < 0) {
+                nd.child[k] = ~(int32_t)(((uint32_t)(~c) << 3) | 1u);
+            } else {
+                const int2 r = ranges[c];
+                const int count = r.y - r.x + 1;
+                if (count <= kLeafMax) {
+                    nd.child[k] = ~(int32_t)(((uint32_t)r.x << 3) | (uint32_t)count);
+                } else {
+                    nd.child[k] = (int32_t)(base + (uint32_t)j);
+                    qOut[qbase + (uint32_t)j] = make_int2(c, (int)(base + (uint32_t)j));
+                    j++;
+                }
+            }
+        } else {
+            // unused slot: inverted box, empty leaf
+#pragma unroll
+            for (int a = 0; a < 3; a++) ql[a] |= 255u << (8 * k);
+            nd.child[k] = ~(int32_t)0;
+        }
+    }
+    nd.lox = ql[0]; nd.loy = ql[1]; nd.loz = ql[2];
+    nd.hix = qh[0]; nd.hiy = qh[1]; nd.hiz = qh[2];
+    nodes[task.y] = nd;
+}
+
+// single-triangle scene: one node whose first slot is the triangle's leaf
 __global__ void emit_single_kernel(const float* __restrict__ boxes, BvhNode* __restrict__ nodes)
 {
+    const float kBig = 1e30f;
     BvhNode nd;
-    for (int k = 0; k < 3; k++) {
-        nd.lmin[k] = boxes[k]; nd.lmax[k] = boxes[3 + k];
-        nd.rmin[k] = FLT_MAX; nd.rmax[k] = -FLT_MAX;
+    float lo[3], hi[3], sc[3];
+    uint32_t qh[3];
+    for (int a = 0; a < 3; a++) {
+        lo[a] = __builtin_fminf(__builtin_fmaxf(boxes[a], -kBig), kBig);
+        hi[a] = __builtin_fmaxf(__builtin_fminf(boxes[3 + a], kBig), -kBig);
+        const float ext = hi[a] - lo[a];
+        int e;
+        const float m = frexpf(ext * (1.0f / 250.0f), &e);
+        e = (ext > 0.0f) ? (m == 0.5f ? e - 1 : e) : -120;
+        if (e < -120) e = -120;
+        sc[a] = ldexpf(1.0f, e);
+        int q1 = (int)ceilf(ext / sc[a]);
+        q1 = q1 < 0 ? 0 : (q1 > 255 ? 255 : q1);
+        while (q1 < 255 && lo[a] + (float)q1 * sc[a] < hi[a]) q1++;
+        qh[a] = (uint32_t)q1;
     }
-    nd.left = ~(int32_t)0; nd.right = ~(int32_t)0;
-    nd.pad[0] = nd.pad[1] = 0;
+    nd.ox = lo[0]; nd.oy = lo[1]; nd.oz = lo[2];
+    nd.sx = sc[0]; nd.sy = sc[1]; nd.sz = sc[2];
+    nd.lox = nd.loy = nd.loz = 0xFFFFFF00u;
+    nd.hix = qh[0]; nd.hiy = qh[1]; nd.hiz = qh[2];
+    nd.child[0] = ~(int32_t)1;   // first 0, count 1
+    nd.child[1] = nd.child[2] = nd.child[3] = ~(int32_t)0;
     nodes[0] = nd;
 }
 
@@ -307,14 +430,16 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
     out.nNodes = nInternal;
 
     // scratch
-    uint32_t *dBounds = nullptr, *keysA = nullptr, *keysB = nullptr, *valsA = nullptr, *valsB = nullptr, *done = nullptr,
-             *remaining = nullptr;
+    uint32_t *dBounds = nullptr, *valsA = nullptr, *valsB = nullptr, *done = nullptr, *remaining = nullptr;
+    unsigned long long *keysA = nullptr, *keysB = nullptr;
+    int2 *queueA = nullptr, *queueB = nullptr;
     float* boxes = nullptr;
     int2 *children = nullptr, *ranges = nullptr;
     void* sortTmp = nullptr;
     auto cleanup = [&]() {
         hipFree(dBounds); hipFree(keysA); hipFree(keysB); hipFree(valsA); hipFree(valsB); hipFree(done);
         hipFree(remaining); hipFree(boxes); hipFree(children); hipFree(ranges); hipFree(sortTmp);
+        hipFree(queueA); hipFree(queueB);
     };
 #define RT_HIPC(call)                                                                                        \
     do {                                                                                                     \
@@ -340,17 +465,17 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
     }
     out.sceneMaxAbs = maxAbs;
 
-    RT_HIPC(hipMalloc((void**)&keysA, sizeof(uint32_t) * (size_t)nTris));
-    RT_HIPC(hipMalloc((void**)&keysB, sizeof(uint32_t) * (size_t)nTris));
+    RT_HIPC(hipMalloc((void**)&keysA, sizeof(unsigned long long) * (size_t)nTris));
+    RT_HIPC(hipMalloc((void**)&keysB, sizeof(unsigned long long) * (size_t)nTris));
     RT_HIPC(hipMalloc((void**)&valsA, sizeof(uint32_t) * (size_t)nTris));
     RT_HIPC(hipMalloc((void**)&valsB, sizeof(uint32_t) * (size_t)nTris));
     hipLaunchKernelGGL(morton_kernel, dim3(grid), dim3(256), 0, stream, out.triRef, nTris, dBounds, keysA, valsA);
     RT_HIPC(hipGetLastError());
 
     size_t tmpBytes = 0;
-    RT_HIPC(rocprim::radix_sort_pairs(nullptr, tmpBytes, keysA, keysB, valsA, valsB, (size_t)nTris, 0, 30, stream));
+    RT_HIPC(rocprim::radix_sort_pairs(nullptr, tmpBytes, keysA, keysB, valsA, valsB, (size_t)nTris, 0, 63, stream));
     RT_HIPC(hipMalloc(&sortTmp, tmpBytes ? tmpBytes : 16));
-    RT_HIPC(rocprim::radix_sort_pairs(sortTmp, tmpBytes, keysA, keysB, valsA, valsB, (size_t)nTris, 0, 30, stream));
+    RT_HIPC(rocprim::radix_sort_pairs(sortTmp, tmpBytes, keysA, keysB, valsA, valsB, (size_t)nTris, 0, 63, stream));
 
     RT_HIPC(hipMalloc((void**)&boxes, sizeof(float) * 6 * (size_t)(2 * (size_t)nTris)));
     hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(256), 0, stream, out.triRef, valsB, nTris, out.triLeaf, boxes);
@@ -390,9 +515,28 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
     }
     if (!fitted) { err = "BVH box fit did not converge in 128 passes"; cleanup(); return false; }
 
-    hipLaunchKernelGGL(emit_kernel, dim3(gridI), dim3(256), 0, stream, children, ranges, boxes, nInt, (int)nTris, out.nodes);
-    RT_HIPC(hipGetLastError());
+    // collapse: `remaining` doubles as the next level's task count, done[0] as the node allocator
+    RT_HIPC(hipMalloc((void**)&queueA, sizeof(int2) * (size_t)nInt));
+    RT_HIPC(hipMalloc((void**)&queueB, sizeof(int2) * (size_t)nInt));
+    const int2 rootTask = make_int2(0, 0);
+    const uint32_t one = 1;
+    RT_HIPC(hipMemcpyAsync(queueA, &rootTask, sizeof(rootTask), hipMemcpyHostToDevice, stream));
+    RT_HIPC(hipMemcpyAsync(done, &one, sizeof(one), hipMemcpyHostToDevice, stream));
+    uint32_t qCount = 1;
+    for (int level = 0; qCount > 0; level++) {
+        if (level > 4 * kStackDepth) { err = "BVH collapse did not terminate"; cleanup(); return false; }
+        RT_HIPC(hipMemsetAsync(remaining, 0, sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(collapse_kernel, dim3((qCount + 255) / 256), dim3(256), 0, stream, children, ranges, boxes,
+                           (int)nTris, queueA, qCount, queueB, remaining, done, out.nodes);
+        RT_HIPC(hipGetLastError());
+        RT_HIPC(hipMemcpyAsync(&qCount, remaining, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        RT_HIPC(hipStreamSynchronize(stream));
+        int2* t = queueA; queueA = queueB; queueB = t;
+    }
+    uint32_t nNodes = 0;
+    RT_HIPC(hipMemcpyAsync(&nNodes, done, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     RT_HIPC(hipStreamSynchronize(stream));
+    out.nNodes = nNodes;
     cleanup();
     return true;
 #undef RT_HIPC

@@ -13,8 +13,8 @@ namespace rt {
 
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
 constexpr int kLeafMax = 4;        // triangles per BVH leaf
-constexpr int kStackDepth = 64;    // >= 30 Morton bits + 24 index bits + margin
-constexpr int kLdsStack = 24;      // entries per lane kept in LDS; deeper entries spill to scratch
+constexpr int kStackDepth = 128;   // exact kernels: up to 3 pushes per level of the four-wide tree
+constexpr int kLdsStack = 32;      // entries per lane kept in LDS; deeper entries spill to scratch
 constexpr int kBlock = 256;        // workgroup size of every tracing kernel
 constexpr int kCounterSlots = 256; // statistics counters are striped over this many 128-byte lines
 constexpr int kCounterStride = 16; // u64 per slot
@@ -63,14 +63,23 @@ struct DevMaterial { // 64 B
 };
 static_assert(sizeof(DevMaterial) == 64, "DevMaterial layout");
 
-// 64 B binary BVH node: both child boxes live in the parent, so one node fetch (four 16-byte
-// loads, one 64-byte segment) decides both children.
-// child >= 0: internal node index; child < 0: leaf, ~child = (first << 3) | (count - 1)
+// 64 B four-wide BVH node with quantised child boxes (after Ylitie, Karras & Laine 2017,
+// "Efficient incoherent ray traversal on GPUs through compressed wide BVHs").  Measured on MI355X
+// (tools/ubench/gather.hip): a divergent per-lane fetch of a 64-byte record costs ~3 cycles per
+// lane of CU throughput when the table is L2-resident and a 128-byte record ~8; beyond L2 the cost
+// is per request (~10 cycles per lane) whatever the size.  So the node count per ray has to drop
+// without the node growing: four children per 64-byte fetch.
+// Child boxes are stored as 8-bit offsets from the node's own box: plane = origin + q * scale,
+// scale a power of two per axis, lower planes rounded down and upper planes rounded up, so a
+// decoded box always contains the exact one.
+// child >= 0: internal node index; child < 0: leaf, ~child = (first << 3) | count, count 0..kLeafMax
+// (count 0 = unused slot, whose box is also inverted: lo = 255, hi = 0).
 struct BvhNode {
-    float lmin[3], lmax[3];
-    float rmin[3], rmax[3];
-    int32_t left, right;
-    uint32_t pad[2];
+    float ox, oy, oz;        // origin = lower corner of the node's box
+    float sx, sy, sz;        // scale per axis (power of two)
+    uint32_t lox, loy, loz;  // byte c = child c
+    uint32_t hix, hiy, hiz;
+    int32_t child[4];
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode layout");
 

@@ -245,7 +245,7 @@ struct LaneStats {
 // MODE 2 / 3: BVH with the exact in-order emulation inline for rays inside the tie band
 //             (redo launch / rt_trace_rays)
 template <int MODE>
-__device__ __forceinline__ Hit closest_hit(const SceneView& s, Ray& ray, const Stack& stack, LaneStats& st, bool& danger)
+__device__ __forceinline__ Hit closest_hit(const SceneView& s, Ray& ray, Stack& stack, LaneStats& st, bool& danger)
 {
     st.rays++;
     if (MODE == 1) return trace_brute(s, ray, st.triBrute);
@@ -376,8 +376,13 @@ __device__ __forceinline__ void flush_stats(const RenderArgs& a, const LaneStats
 {
     const int lane = threadIdx.x & 63;
     uint32_t v0 = st.rays, v1 = st.slow, v2 = st.bvh.nodes, v3 = st.bvh.tris + st.triBrute, v4 = st.hits;
+    uint32_t v5 = st.bvh.idleA, v6 = st.bvh.idleB;
+#ifdef RT_LOOP_TIMERS
+    v1 = st.bvh.diagA; v4 = st.bvh.diagB; // diagnostic build: wave-level loop iterations replace slow-path rays / hits
+#endif
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
+        v5 += __shfl_xor(v5, off); v6 += __shfl_xor(v6, off);
         v0 += __shfl_xor(v0, off);
         v1 += __shfl_xor(v1, off);
         v2 += __shfl_xor(v2, off);
@@ -389,9 +394,10 @@ __device__ __forceinline__ void flush_stats(const RenderArgs& a, const LaneStats
     if (lane == 0) {
         atomicAdd(&wgCnt[0], v0); atomicAdd(&wgCnt[1], v1); atomicAdd(&wgCnt[2], v2);
         atomicAdd(&wgCnt[3], v3); atomicAdd(&wgCnt[4], v4);
+        atomicAdd(&wgCnt[5], v5); atomicAdd(&wgCnt[6], v6);
     }
     __syncthreads();
-    if (threadIdx.x < 5) {
+    if (threadIdx.x < 7) {
         const uint32_t v = wgCnt[threadIdx.x];
         if (v) atomicAdd(a.counters + (size_t)(blockIdx.x % kCounterSlots) * kCounterStride + threadIdx.x, (unsigned long long)v);
     }
@@ -407,30 +413,32 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Hot kernel: persistent wavefronts with path regeneration.
+// Hot kernel: persistent wavefronts, path regeneration, resumable traversal.
 //
 // A lane owns one PIXEL at a time and walks all of its samples in the reference's summation order
 // (z-lane major: s = z, z+4, z+8, ... for z = 0..3; the per-z partial sums are then added in z
 // order, GPURaytracer.cu:88-116), so no cross-lane reduction is needed.  The wave runs one loop:
-//   (1) lanes whose path ended start their next sample, or finish their pixel and take a new
-//       one from the wave's pool (an 8x8 tile fetched with ONE atomic per 64 pixels from 8 striped
-//       counters; the workgroups that share an XCD drain the same contiguous band of tiles first);
-//   (2) every lane that holds a ray runs one closest-hit query;
-//   (3) miss -> sky, hit -> shade and spawn the bounce ray.
-// All 64 lanes therefore carry a ray into every traversal, whatever the path lengths; in the
-// reference (and in the tile kernel below) a wave keeps paying for its longest path while the lanes
-// that missed sit idle.
-__global__ __launch_bounds__(256, 4) void path_kernel(const RenderArgs a)
+//   (1) lanes whose closest-hit query has finished are shaded (miss -> sky, hit -> material + BRDF
+//       + bounce ray); lanes whose path ended start their next sample, or finish their pixel and
+//       take a new one from the wave's pool (an 8x8 tile fetched with ONE atomic per 64 pixels
+//       from 8 striped counters; the workgroups that share an XCD drain the same band of tiles);
+//   (2) every lane that holds a ray (re)enters the traversal loops, which the wave leaves again
+//       as soon as fewer than kKeepNum/kKeepDen of the entering lanes are still traversing.
+// Traversal therefore always runs with most lanes busy, whatever the path lengths and however
+// uneven the rays; in the reference (and in the tile kernel below) a wave pays for its longest
+// path and its longest ray while the other lanes sit idle.
+constexpr int kKeepNum = 3, kKeepDen = 8;
+
+__global__ __launch_bounds__(256, 3) void path_kernel(const RenderArgs a)
 {
     __shared__ uint32_t ldsStack[kLdsStack * kBlock];
     __shared__ uint32_t poolSlot[kBlock];
     __shared__ uint32_t wgCnt[8];
-    uint32_t ovf[kStackDepth - kLdsStack];
-    Stack stack; stack.lds = ldsStack + threadIdx.x; stack.ovf = ovf;
+    HotStack stack; stack.lds = ldsStack + threadIdx.x; stack.dropped = false;
     const int lane = threadIdx.x & 63;
     uint32_t* slot = poolSlot + (threadIdx.x & ~63);
 
-    LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
+    LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0; st.bvh.idleA = 0; st.bvh.idleB = 0;
 
     // wave-uniform work pool
     const uint32_t nTiles = (uint32_t)a.tiles8X * (uint32_t)a.tiles8Y;
@@ -451,9 +459,33 @@ __global__ __launch_bounds__(256, 4) void path_kernel(const RenderArgs a)
     float tr = 0.0f, tg = 0.0f, tb = 0.0f;   // sum over z lanes
     PathAcc acc; acc.ox = acc.oy = acc.oz = 0.0f; acc.bx = acc.by = acc.bz = 1.0f;
     Ray ray; ray.ox = ray.oy = ray.oz = ray.dx = ray.dy = ray.dz = 0.0f; ray.maxDist = 0.0f;
+    Trav T; trav_begin(T, a.scene, ray, stack); T.node = kTravEnd;
     const uint32_t spp = a.sampleCount;
 
     for (;;) {
+#ifdef RT_PHASE_TIMERS
+        const long long tp0 = clock64();
+#endif
+        // ---- (1) shade the lanes whose closest-hit query is complete
+        if (hasPath && !trav_running(T)) {
+            bool danger = false;
+            const Hit h = trav_finish(T, a.scene, ray, danger);
+            if (danger) { flagged = true; st.slow++; }
+            if (stack.dropped) { flagged = true; stack.dropped = false; } // stack overflow: the redo launch has the deep stack
+            const uint32_t sidx = iter * 4u + z;
+            const bool more = shade_segment(a, h, ray, seed, sidx, bounce, acc, st, checksum, primary);
+            bounce++;
+            if (more) {
+                st.rays++;
+                trav_begin(T, a.scene, ray, stack);
+            } else {
+                hasPath = false;
+                // exposureCorrection (:690-698), per sample, then :102-104
+                pr += 1.0f - rtd::exp_f(-acc.ox * a.exposure);
+                pg += 1.0f - rtd::exp_f(-acc.oy * a.exposure);
+                pb += 1.0f - rtd::exp_f(-acc.oz * a.exposure);
+            }
+        }
         // ---- (1a) lanes whose path ended: next sample of the pixel, or the pixel is finished
         if (hasPixel && !hasPath) {
             iter++;
@@ -516,8 +548,7 @@ __global__ __launch_bounds__(256, 4) void path_kernel(const RenderArgs a)
             }
             __builtin_amdgcn_wave_barrier();
             const unsigned long long taken = __ballot(want && rank < avail);
-            // clear the bits that were handed out: they are the lowest popc(taken) set bits
-            int k = __popcll(taken);
+            int k = __popcll(taken); // the bits handed out are the lowest popc(taken) set bits
             unsigned long long m = poolMask;
             while (k-- > 0) m &= m - 1ull;
             poolMask = m;
@@ -531,7 +562,10 @@ __global__ __launch_bounds__(256, 4) void path_kernel(const RenderArgs a)
             acc.ox = acc.oy = acc.oz = 0.0f; acc.bx = acc.by = acc.bz = 1.0f;
             bounce = 0;
             hasPath = a.bounceCount > 0;
-            if (!hasPath) { // bounceCount <= 0: the bounce loop does not run, radiance 0
+            if (hasPath) {
+                st.rays++;
+                trav_begin(T, a.scene, ray, stack);
+            } else { // bounceCount <= 0: the bounce loop does not run, radiance 0
                 pr += 1.0f - rtd::exp_f(-0.0f * a.exposure);
                 pg += 1.0f - rtd::exp_f(-0.0f * a.exposure);
                 pb += 1.0f - rtd::exp_f(-0.0f * a.exposure);
@@ -539,22 +573,17 @@ __global__ __launch_bounds__(256, 4) void path_kernel(const RenderArgs a)
         }
         if (__ballot(hasPixel) == 0ull) break; // every lane is idle and no tile is left
 
-        // ---- (2) + (3) one path segment for every lane that holds a ray
-        if (hasPath) {
-            bool danger = false;
-            const Hit h = closest_hit<0>(a.scene, ray, stack, st, danger);
-            flagged = flagged || danger;
-            const uint32_t sidx = iter * 4u + z;
-            const bool more = shade_segment(a, h, ray, seed, sidx, bounce, acc, st, checksum, primary);
-            bounce++;
-            if (!more) {
-                hasPath = false;
-                // exposureCorrection (:690-698), per sample, then :102-104
-                pr += 1.0f - rtd::exp_f(-acc.ox * a.exposure);
-                pg += 1.0f - rtd::exp_f(-acc.oy * a.exposure);
-                pb += 1.0f - rtd::exp_f(-acc.oz * a.exposure);
-            }
-        }
+        // ---- (2) traversal burst for every lane with an unfinished query
+        const bool running = hasPath && trav_running(T);
+        const int nRun = __popcll(__ballot(running));
+#ifdef RT_PHASE_TIMERS
+        const long long tp1 = clock64();
+#endif
+        if (running) trav_burst(T, a.scene, ray, stack, st.bvh, (nRun * kKeepNum + kKeepDen - 1) / kKeepDen);
+#ifdef RT_PHASE_TIMERS
+        // diagnostic build: wave cycles outside / inside the traversal burst (reported through the idle-lane slots, /64)
+        if (lane == 0) { st.bvh.idleB += (uint32_t)((tp1 - tp0) >> 6); st.bvh.idleA += (uint32_t)((clock64() - tp1) >> 6); }
+#endif
     }
     flush_stats(a, st, wgCnt);
 }
@@ -564,7 +593,7 @@ __global__ __launch_bounds__(256, 4) void path_kernel(const RenderArgs a)
 // loops.  Used for the brute-force mode (MODE 1, whole tile) and for the redo launch (MODE 2,
 // pixel list written by path_kernel).  LOG2L: log2 of the sample lanes per pixel (0, 1, 2).
 template <int MODE>
-__device__ __forceinline__ V4 trace_path(const RenderArgs& a, Ray& ray, uint32_t& seed, uint32_t sample, const Stack& stack,
+__device__ __forceinline__ V4 trace_path(const RenderArgs& a, Ray& ray, uint32_t& seed, uint32_t sample, Stack& stack,
                                          LaneStats& st, uint32_t& checksum, uint32_t* primary)
 {
     PathAcc p; p.ox = p.oy = p.oz = 0.0f; p.bx = p.by = p.bz = 1.0f;
@@ -589,7 +618,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs a)
     __shared__ uint32_t wgCnt[8];
     uint32_t ovf[kStackDepth - kLdsStack];
     Stack stack; stack.lds = ldsStack + threadIdx.x; stack.ovf = ovf;
-    LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
+    LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0; st.bvh.idleA = 0; st.bvh.idleB = 0;
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t z = (uint32_t)(lane & (L - 1));
@@ -668,7 +697,7 @@ __global__ __launch_bounds__(256) void trace_rays_kernel(SceneView s, const floa
     __shared__ uint32_t ldsStack[kLdsStack * kBlock];
     uint32_t ovf[kStackDepth - kLdsStack];
     Stack stack; stack.lds = ldsStack + threadIdx.x; stack.ovf = ovf;
-    LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
+    LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0; st.bvh.idleA = 0; st.bvh.idleB = 0;
     bool danger = false;
     const Hit h = closest_hit<MODE>(s, ray, stack, st, danger);
     uint4 o = make_uint4(kNoHit, kNoHit, kNoHit, kNoHit);
@@ -703,7 +732,7 @@ void launch_render(const RenderArgs& a, int mode, int numCUs, hipStream_t stream
     b.tiles8Y = (a.y1 - a.y0 + 7) / 8;
     const uint32_t nTiles = (uint32_t)b.tiles8X * (uint32_t)b.tiles8Y;
     // persistent grid: 4 workgroups (16 waves) per CU is what 128 VGPRs admit; never more waves than tiles
-    uint32_t grid = (uint32_t)numCUs * 4u;
+    uint32_t grid = (uint32_t)numCUs * 3u; // persistent grid = what the kernel's 168 VGPRs admit per CU (3 workgroups)
     const uint32_t need = (nTiles + 3u) / 4u;
     if (grid > need) grid = need;
     if (grid < 8u) grid = 8u;

@@ -197,10 +197,12 @@ __device__ __forceinline__ Hit trace_brute(const SceneView& s, Ray& ray, uint32_
 // ------------------------------------------------------------------ BVH
 // Ray-side conservative padding: the slab test is evaluated against two shifted origins, which
 // widens every box by `pad` along each axis in t-space terms (pad * |1/d|) at no per-box cost.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 struct BoxRay {
-    float nox, noy, noz;   // origin for near planes
-    float fox, foy, foz;   // origin for far planes
     float ix, iy, iz;
+    float cnx, cny, cnz;   // -(padded origin for near planes) / d
+    float cfx, cfy, cfz;   // -(padded origin for far planes) / d
     bool sx, sy, sz;       // direction sign bits
 };
 
@@ -209,110 +211,194 @@ __device__ __forceinline__ BoxRay make_box_ray(const Ray& r, float sceneMaxAbs)
     BoxRay b;
     const float scale = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(r.ox), __builtin_fabsf(r.oy)),
                                         __builtin_fmaxf(__builtin_fabsf(r.oz), sceneMaxAbs));
-    const float pad = scale * 3.8146973e-06f + 1e-30f; // 2^-18 relative: 32 ulps of the largest coordinate
+    // 2^-18 relative: 32 ulps of the largest coordinate.  The plane distances below are evaluated
+    // as fma(plane, 1/d, -o/d), whose rounding error is half an ulp of |o| in plane position:
+    // far inside the pad.
+    const float pad = scale * 3.8146973e-06f + 1e-30f;
     b.ix = 1.0f / r.dx; b.iy = 1.0f / r.dy; b.iz = 1.0f / r.dz;
     b.sx = __builtin_signbit(r.dx); b.sy = __builtin_signbit(r.dy); b.sz = __builtin_signbit(r.dz);
-    b.nox = b.sx ? r.ox - pad : r.ox + pad;  b.fox = b.sx ? r.ox + pad : r.ox - pad;
-    b.noy = b.sy ? r.oy - pad : r.oy + pad;  b.foy = b.sy ? r.oy + pad : r.oy - pad;
-    b.noz = b.sz ? r.oz - pad : r.oz + pad;  b.foz = b.sz ? r.oz + pad : r.oz - pad;
+    b.cnx = -((b.sx ? r.ox - pad : r.ox + pad) * b.ix);  b.cfx = -((b.sx ? r.ox + pad : r.ox - pad) * b.ix);
+    b.cny = -((b.sy ? r.oy - pad : r.oy + pad) * b.iy);  b.cfy = -((b.sy ? r.oy + pad : r.oy - pad) * b.iy);
+    b.cnz = -((b.sz ? r.oz - pad : r.oz + pad) * b.iz);  b.cfz = -((b.sz ? r.oz + pad : r.oz - pad) * b.iz);
     return b;
 }
 
-// returns entry distance (clamped at 0) or +inf-like miss via the bool
-__device__ __forceinline__ bool box_test(const BoxRay& b, const float* __restrict__ mn, const float* __restrict__ mx,
-                                         float bound, float& tnear)
+// Slab test of the four children of a node.  The test is internal to the product (the oracle has
+// no BVH): it only has to be conservative, which the quantisation (outward rounding) and the pad
+// ensure.  With plane = origin + q * scale, the distance to a plane is
+//   (plane - o) / d = q * (scale / d) + (origin - o) / d = fma(q, a, b)
+// with a, b per node and axis, so a child costs one byte-to-float conversion and one FMA per plane.
+// fmax/fmin drop NaN operands (0 * inf or inf - inf when a direction component is zero): the axis
+// is then ignored, which errs on the side of visiting.
+// key[c] = bits of the entry distance (>= 0, so unsigned order = float order) or ~0 for a miss.
+constexpr uint32_t kMissKey = 0xFFFFFFFFu;
+
+__device__ __forceinline__ f2 ubyte2_f(uint32_t v, int c) { return (f2){ (float)((v >> (8 * c)) & 0xFFu), (float)((v >> (8 * c + 8)) & 0xFFu) }; }
+__device__ __forceinline__ f2 splat2(float v) { return (f2){ v, v }; }
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+__device__ __forceinline__ void node_test(const BoxRay& b, const float4& N0, const uint4& N1, const uint4& N2, float bound,
+                                          uint32_t key[4])
 {
-    const float nx = b.sx ? mx[0] : mn[0], fx = b.sx ? mn[0] : mx[0];
-    const float ny = b.sy ? mx[1] : mn[1], fy = b.sy ? mn[1] : mx[1];
-    const float nz = b.sz ? mx[2] : mn[2], fz = b.sz ? mn[2] : mx[2];
-    const float t0x = (nx - b.nox) * b.ix, t1x = (fx - b.fox) * b.ix;
-    const float t0y = (ny - b.noy) * b.iy, t1y = (fy - b.foy) * b.iy;
-    const float t0z = (nz - b.noz) * b.iz, t1z = (fz - b.foz) * b.iz;
-    // __builtin_fmaxf/fminf drop NaN operands (0 * inf when a zero direction component meets a
-    // padded plane exactly); such a ray is `pad` away from anything inside the box.
-    const float tn = __builtin_fmaxf(__builtin_fmaxf(t0x, t0y), __builtin_fmaxf(t0z, 0.0f));
-    const float tf = __builtin_fminf(__builtin_fminf(t1x, t1y), __builtin_fminf(t1z, bound));
-    tnear = tn;
-    return tn <= tf;
+    // N0 = ox oy oz sx | N1 = sy sz lox loy | N2 = loz hix hiy hiz
+    const f2 ax = splat2(N0.w * b.ix), ay = splat2(__uint_as_float(N1.x) * b.iy), az = splat2(__uint_as_float(N1.y) * b.iz);
+    const f2 bnx = splat2(__builtin_fmaf(N0.x, b.ix, b.cnx)), bfx = splat2(__builtin_fmaf(N0.x, b.ix, b.cfx));
+    const f2 bny = splat2(__builtin_fmaf(N0.y, b.iy, b.cny)), bfy = splat2(__builtin_fmaf(N0.y, b.iy, b.cfy));
+    const f2 bnz = splat2(__builtin_fmaf(N0.z, b.iz, b.cnz)), bfz = splat2(__builtin_fmaf(N0.z, b.iz, b.cfz));
+    const uint32_t qnx = b.sx ? N2.y : N1.z, qfx = b.sx ? N1.z : N2.y;
+    const uint32_t qny = b.sy ? N2.z : N1.w, qfy = b.sy ? N1.w : N2.z;
+    const uint32_t qnz = b.sz ? N2.w : N2.x, qfz = b.sz ? N2.x : N2.w;
+#pragma unroll
+    for (int c = 0; c < 4; c += 2) {
+        const f2 t0x = pk_fma(ubyte2_f(qnx, c), ax, bnx), t1x = pk_fma(ubyte2_f(qfx, c), ax, bfx);
+        const f2 t0y = pk_fma(ubyte2_f(qny, c), ay, bny), t1y = pk_fma(ubyte2_f(qfy, c), ay, bfy);
+        const f2 t0z = pk_fma(ubyte2_f(qnz, c), az, bnz), t1z = pk_fma(ubyte2_f(qfz, c), az, bfz);
+        const float tn0 = __builtin_fmaxf(__builtin_fmaxf(t0x.x, t0y.x), __builtin_fmaxf(t0z.x, 0.0f));
+        const float tn1 = __builtin_fmaxf(__builtin_fmaxf(t0x.y, t0y.y), __builtin_fmaxf(t0z.y, 0.0f));
+        const float tf0 = __builtin_fminf(__builtin_fminf(t1x.x, t1y.x), __builtin_fminf(t1z.x, bound));
+        const float tf1 = __builtin_fminf(__builtin_fminf(t1x.y, t1y.y), __builtin_fminf(t1z.y, bound));
+        key[c] = tn0 <= tf0 ? __float_as_uint(tn0) : kMissKey;
+        key[c + 1] = tn1 <= tf1 ? __float_as_uint(tn1) : kMissKey;
+    }
 }
 
-struct BvhCounters { uint32_t nodes, tris; };
+struct BvhCounters { uint32_t nodes, tris; uint32_t idleA = 0, idleB = 0; uint32_t diagA = 0, diagB = 0; };
 
-// Traversal stack: the first kLdsStack entries of every lane live in LDS, laid out
-// [entry][lane] so that lanes at the same depth hit distinct banks (ds latency ~64 cycles vs a
-// scratch round trip through L1/L2); deeper entries, rare, spill to a per-lane scratch array.
+#ifdef RT_UTIL_COUNTERS
+// diagnostic build: lanes idle while the wave runs a traversal-loop body (first active lane counts)
+__device__ __forceinline__ void count_idle(uint32_t& acc)
+{
+    const unsigned long long m = __ballot(true);
+    if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) acc += 64u - (uint32_t)__popcll(m);
+}
+#else
+__device__ __forceinline__ void count_idle(uint32_t&) {}
+#endif
+
+// Traversal stacks.  Entries live in LDS, laid out [entry][lane] so that lanes at the same depth
+// hit distinct banks (ds latency ~64 cycles vs a scratch round trip through L1/L2).  Entry 0 holds
+// the end-of-traversal sentinel, so a pop needs no emptiness test.
+constexpr int32_t kTravEnd = 0x7FFFFFFF; // traversal finished / no leaf parked (internal nodes are < kTravEnd, leaves < 0)
+
+// Full-depth stack of the exact kernels: entries beyond kLdsStack spill to a per-lane scratch array.
 struct Stack {
     uint32_t* lds;   // already offset by the lane's slot
     uint32_t* ovf;   // kStackDepth - kLdsStack entries of private memory
-    __device__ __forceinline__ void push(int& sp, uint32_t v) const
+    __device__ __forceinline__ void reset(int& sp) { lds[0] = (uint32_t)kTravEnd; sp = 1; }
+    __device__ __forceinline__ void push(int& sp, uint32_t v)
     {
         if (sp < kLdsStack) lds[sp * kBlock] = v;
         else if (sp < kStackDepth) ovf[sp - kLdsStack] = v;
         sp++;
     }
-    __device__ __forceinline__ uint32_t pop(int& sp) const
+    __device__ __forceinline__ uint32_t pop(int& sp)
     {
         --sp;
         if (sp < kLdsStack) return lds[sp * kBlock];
-        return sp < kStackDepth ? ovf[sp - kLdsStack] : 0u;
+        return sp < kStackDepth ? ovf[sp - kLdsStack] : (uint32_t)kTravEnd;
+    }
+    // h hit children sorted front to back (c[0] is entered at once): push c[h-1] .. c[1]
+    __device__ __forceinline__ void push_far(int& sp, int h, uint32_t c1, uint32_t c2, uint32_t c3)
+    {
+        if (h >= 4) push(sp, c3);
+        if (h >= 3) push(sp, c2);
+        if (h >= 2) push(sp, c1);
+    }
+};
+
+// LDS-only stack of the hot kernel: a push beyond kLdsStack entries is dropped and remembered; the
+// pixel is then re-rendered by the redo launch (which uses Stack), so the hot loops carry no
+// scratch path at all.
+struct HotStack {
+    uint32_t* lds;
+    bool dropped;
+    __device__ __forceinline__ void reset(int& sp) { lds[0] = (uint32_t)kTravEnd; sp = 1; }
+    __device__ __forceinline__ void push(int& sp, uint32_t v)
+    {
+        if (sp < kLdsStack) { lds[sp * kBlock] = v; sp++; }
+        else dropped = true;
+    }
+    __device__ __forceinline__ uint32_t pop(int& sp) { --sp; return lds[sp * kBlock]; }
+    // three independent predicated stores, no bounds test per entry
+    __device__ __forceinline__ void push_far(int& sp, int h, uint32_t c1, uint32_t c2, uint32_t c3)
+    {
+        if (sp + 3 > kLdsStack) { dropped = dropped || h >= 2; return; }
+        uint32_t* top = lds + (sp + h) * kBlock;
+        if (h >= 2) top[-2 * kBlock] = c1;
+        if (h >= 3) top[-3 * kBlock] = c2;
+        if (h >= 4) top[-4 * kBlock] = c3;
+        sp += h >= 2 ? h - 1 : 0;
     }
 };
 
 // Band inside which a hit on a different object triggers the exact in-order emulation.
 __device__ __forceinline__ float band_of(float t, float rayScale) { return 2e-4f * (t + rayScale); }
 
-// Generic stack traversal.  `Visit` is called for every triangle of every reached leaf with its
-// leaf-order record; it returns the (possibly reduced) prune bound.
-// "while-while" traversal (Aila & Laine 2009): a lane that reaches a leaf parks it and keeps
-// descending until every lane of the wave still searching has a leaf too; then the wave runs the
-// triangle tests together.  Node visits and triangle tests no longer serialise against each other
-// inside a wave (VALU lane utilisation of the first kernel was 32 %).
-template <class Visit>
-__device__ __forceinline__ void bvh_walk(const SceneView& s, const BoxRay& br, float bound, const Stack& stack,
+// One node visit of a lane: test the four children, sort the hit ones front to back (sorting
+// network on (distance, child) pairs), enter the nearest, push the others farthest first; pop when
+// none is hit.  On return `node` is the next node: internal (>= 0), a leaf (< 0) or kTravEnd.
+__device__ __forceinline__ void cmp_swap(uint32_t& ka, uint32_t& kb, int32_t& ia, int32_t& ib)
+{
+    const bool sw = kb < ka;
+    const uint32_t k0 = sw ? kb : ka, k1 = sw ? ka : kb;
+    const int32_t i0 = sw ? ib : ia, i1 = sw ? ia : ib;
+    ka = k0; kb = k1; ia = i0; ib = i1;
+}
+
+template <class STACK>
+__device__ __forceinline__ void node_step(const SceneView& s, const BoxRay& br, float bound, STACK& stack, int& sp,
+                                          int32_t& node)
+{
+    const float4* np = reinterpret_cast<const float4*>(s.nodes + node);
+    const float4 N0 = np[0];
+    const uint4 N1 = reinterpret_cast<const uint4*>(np)[1], N2 = reinterpret_cast<const uint4*>(np)[2];
+    const int4 CH = reinterpret_cast<const int4*>(np)[3];
+    uint32_t k[4];
+    node_test(br, N0, N1, N2, bound, k);
+    int32_t c0 = CH.x, c1 = CH.y, c2 = CH.z, c3 = CH.w;
+    const int h = (k[0] != kMissKey) + (k[1] != kMissKey) + (k[2] != kMissKey) + (k[3] != kMissKey);
+    cmp_swap(k[0], k[1], c0, c1); cmp_swap(k[2], k[3], c2, c3);
+    cmp_swap(k[0], k[2], c0, c2); cmp_swap(k[1], k[3], c1, c3);
+    cmp_swap(k[1], k[2], c1, c2);
+    stack.push_far(sp, h, (uint32_t)c1, (uint32_t)c2, (uint32_t)c3);
+    node = c0;
+    if (h == 0) node = (int32_t)stack.pop(sp);
+}
+
+template <class STACK, class Visit>
+__device__ __forceinline__ void bvh_walk(const SceneView& s, const BoxRay& br, float bound, STACK& stack,
                                          BvhCounters& cnt, Visit&& visit)
 {
     if (!s.rootIsValid) return;
-    constexpr int32_t kEnd = 0x7FFFFFFF; // traversal finished / no leaf parked (internal nodes are < kEnd, leaves < 0)
-    int sp = 0;
+    int sp;
+    stack.reset(sp);
     int32_t node = 0; // root
-    int32_t leaf = kEnd;
-    while (node != kEnd) {
-        while (node >= 0 && node != kEnd) {
-            const float4* np = reinterpret_cast<const float4*>(s.nodes + node);
-            const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+    int32_t leaf = kTravEnd;
+    while (node != kTravEnd) {
+        while (node >= 0 && node != kTravEnd) {
             cnt.nodes++;
-            const float lmin[3] = { n0.x, n0.y, n0.z }, lmax[3] = { n0.w, n1.x, n1.y };
-            const float rmin[3] = { n1.z, n1.w, n2.x }, rmax[3] = { n2.y, n2.z, n2.w };
-            const int32_t left = __float_as_int(n3.x), right = __float_as_int(n3.y);
-            float tl, tr;
-            const bool hl = box_test(br, lmin, lmax, bound, tl);
-            const bool hr = box_test(br, rmin, rmax, bound, tr);
-            if (hl && hr) {
-                const bool leftFirst = tl <= tr;
-                stack.push(sp, (uint32_t)(leftFirst ? right : left));
-                node = leftFirst ? left : right;
-            } else if (hl) node = left;
-            else if (hr) node = right;
-            else node = sp > 0 ? (int32_t)stack.pop(sp) : kEnd;
-            if (node < 0 && leaf == kEnd) { // park the first leaf, keep searching
+            count_idle(cnt.idleA);
+            node_step(s, br, bound, stack, sp, node);
+            if (node < 0 && leaf == kTravEnd) { // park the first leaf, keep searching
                 leaf = node;
-                node = sp > 0 ? (int32_t)stack.pop(sp) : kEnd;
+                node = (int32_t)stack.pop(sp);
             }
-            if (!__any(leaf == kEnd)) break; // every searching lane holds a leaf
+            if (!__any(leaf == kTravEnd)) break; // every searching lane holds a leaf
         }
-        while (leaf != kEnd) {
+        while (leaf != kTravEnd) {
             const uint32_t code = (uint32_t)(~leaf);
-            const uint32_t first = code >> 3, count = (code & 7u) + 1u;
+            const uint32_t first = code >> 3, count = code & 7u;
             for (uint32_t k = 0; k < count; k++) {
                 const float4* p = reinterpret_cast<const float4*>(s.triLeaf + first + k);
                 const float4 A = p[0], B = p[1], C = p[2];
                 cnt.tris++;
+                count_idle(cnt.idleB);
                 bound = visit(A, B, C, bound);
             }
-            leaf = kEnd;
+            leaf = kTravEnd;
             if (node < 0) { // a second leaf was reached while the first was parked
                 leaf = node;
-                node = sp > 0 ? (int32_t)stack.pop(sp) : kEnd;
+                node = (int32_t)stack.pop(sp);
             }
         }
     }
@@ -335,7 +421,7 @@ __device__ __forceinline__ void cull_lookup(const SceneView& s, const Ray& ray, 
 // Exact emulation of :247-265 restricted to the objects that have an accepted hit with
 // t <= limit (objects beyond cannot change the outcome).
 __device__ __noinline__ Hit trace_bvh_exact(const SceneView& s, Ray& ray, const TriRay& q, const BoxRay& br,
-                                            float limit, const Stack& stack, BvhCounters& cnt)
+                                            float limit, Stack& stack, BvhCounters& cnt)
 {
     Hit best; best.t = FLT_MAX; best.gid = kNoHit; best.b0 = best.b1 = best.b2 = 0.0f;
     const float m0 = ray.maxDist;
@@ -387,7 +473,7 @@ __device__ __noinline__ Hit trace_bvh_exact(const SceneView& s, Ray& ray, const 
 // EXACT = false: the hot render kernel only reports `danger`; the pixel is re-rendered by the
 // redo launch, which keeps the rare path (and its registers) out of the hot kernel.
 template <bool EXACT>
-__device__ __forceinline__ Hit trace_bvh(const SceneView& s, Ray& ray, const Stack& stack, BvhCounters& cnt,
+__device__ __forceinline__ Hit trace_bvh(const SceneView& s, Ray& ray, Stack& stack, BvhCounters& cnt,
                                          uint32_t& slowPath, bool& danger)
 {
     Hit best; best.t = FLT_MAX; best.gid = kNoHit; best.b0 = best.b1 = best.b2 = 0.0f;
@@ -431,9 +517,146 @@ __device__ __forceinline__ Hit trace_bvh(const SceneView& s, Ray& ray, const Sta
     return best;
 }
 
+// ------------------------------------------------------------------ resumable traversal
+// The hot kernel keeps the traversal state of every lane in registers across its main loop, so
+// that a wave can leave the traversal as soon as most of its lanes are done, shade and re-arm
+// those lanes, and come back.
+//
+// Scheduling inside a burst: a lane may have a node to visit (node >= 0), triangles to test
+// (triCount > 0, the rest of one leaf) or both; a second leaf reached while triangles are pending
+// stays in `node` (< 0) and blocks further node visits.  Every iteration the wave runs the kind of
+// step that more lanes are waiting for.  Measured with the while-while loops this replaces, a
+// triangle-loop iteration ran with 16-25 of 64 lanes and a node-loop iteration with 25-33.
+struct Trav {
+    int32_t node;
+    uint32_t triFirst, triCount;
+    int sp;
+    float bound, m0, rayScale;
+    Hit best;
+    uint32_t bestObj;
+    float otherT;
+    CullCache cc;
+    TriRay q;
+    BoxRay br;
+};
+__device__ __forceinline__ void trav_begin(Trav& T, const SceneView& s, const Ray& ray, HotStack& stack)
+{
+    T.q = make_tri_ray(ray);
+    T.br = make_box_ray(ray, s.sceneMaxAbs);
+    T.rayScale = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ray.ox), __builtin_fabsf(ray.oy)),
+                                 __builtin_fmaxf(__builtin_fabsf(ray.oz), s.sceneMaxAbs));
+    T.m0 = ray.maxDist; T.bound = ray.maxDist;
+    T.best.t = FLT_MAX; T.best.gid = kNoHit; T.best.b0 = T.best.b1 = T.best.b2 = 0.0f;
+    T.bestObj = kNoHit; T.otherT = FLT_MAX;
+    T.cc.obj = kNoHit; T.cc.tmin = 0.0f; T.cc.bfar = 0.0f;
+    stack.reset(T.sp); T.triFirst = 0; T.triCount = 0;
+    T.node = s.rootIsValid ? 0 : kTravEnd;
+}
+
+__device__ __forceinline__ bool trav_running(const Trav& T) { return T.node != kTravEnd || T.triCount != 0u; }
+
+// a leaf in `node` becomes the pending triangle range once the previous range is used up
+__device__ __forceinline__ void trav_take_leaf(Trav& T, HotStack& stack)
+{
+    if (T.triCount == 0u && T.node < 0) {
+        const uint32_t code = (uint32_t)(~T.node);
+        T.triFirst = code >> 3; T.triCount = code & 7u;
+        T.node = (int32_t)stack.pop(T.sp);
+    }
+}
+
+__device__ __forceinline__ void trav_tri_step(Trav& T, const SceneView& s, const Ray& ray, HotStack& stack, BvhCounters& cnt)
+{
+    if (T.triCount != 0u) {
+        const float4* p = reinterpret_cast<const float4*>(s.triLeaf + T.triFirst);
+        const float4 A = p[0], B = p[1], C = p[2];
+        T.triFirst++; T.triCount--;
+        cnt.tris++;
+        float t, b0, b1, b2;
+        // The object-space cull of the winner's object (GPURaytracer.cu:267-315) is checked once, in
+        // trav_finish: a hit on an object whose cull fails (flat meshes) sends the pixel to
+        // the redo launch instead of costing every triangle step a 96-byte fetch and a slab test.
+        if (tri_test(ray, T.q, T.m0, A.x, A.y, A.z, B.x, B.y, B.z, C.x, C.y, C.z, t, b0, b1, b2) && t <= T.bound) {
+            const uint32_t gid = __float_as_uint(A.w), obj = __float_as_uint(B.w);
+            const bool better = t < T.best.t || (t == T.best.t && gid < T.best.gid);
+            if (obj != T.bestObj) {
+                if (better) { if (T.best.gid != kNoHit) T.otherT = T.best.t; T.bestObj = obj; }
+                else T.otherT = __builtin_fminf(T.otherT, t);
+            }
+            if (better) {
+                T.best.t = t; T.best.b0 = b0; T.best.b1 = b1; T.best.b2 = b2; T.best.gid = gid;
+                T.bound = __builtin_fminf(T.m0, t + band_of(t, T.rayScale));
+            }
+        }
+    }
+    trav_take_leaf(T, stack);
+}
+
+#ifndef RT_TRI_NUM
+#define RT_TRI_NUM 4
+#endif
+#define RT_TRI_DEN 4
+// Runs traversal steps for the calling lanes (all of them still traversing) until fewer than
+// `keep` of them remain; the others wait at the reconvergence point with their result.
+__device__ __forceinline__ void trav_burst(Trav& T, const SceneView& s, const Ray& ray, HotStack& stack,
+                                           BvhCounters& cnt, int keep)
+{
+#ifdef RT_LOOP_TIMERS
+    const bool leader = (int)(threadIdx.x & 63) == __builtin_ctzll(__ballot(true));
+#endif
+    for (;;) {
+#ifdef RT_LOOP_TIMERS
+        const long long tl0 = clock64();
+#endif
+        const bool wantNode = T.node >= 0 && T.node != kTravEnd;
+        const bool wantTri = T.triCount != 0u || T.node < 0;
+        const int nNode = __popcll(__ballot(wantNode)), nTri = __popcll(__ballot(wantTri));
+        // leave when most of the wave has finished: the finished lanes get shaded and re-armed
+        if (__popcll(__ballot(wantNode || wantTri)) < keep || nNode + nTri == 0) break;
+        if (nTri * RT_TRI_DEN >= nNode * RT_TRI_NUM) {
+            if (wantTri) {
+                count_idle(cnt.idleB);
+#ifdef RT_LOOP_TIMERS
+                if ((int)(threadIdx.x & 63) == __builtin_ctzll(__ballot(true))) cnt.diagB++;
+#endif
+                trav_tri_step(T, s, ray, stack, cnt);
+            }
+#ifdef RT_LOOP_TIMERS
+            if (leader) cnt.idleB += (uint32_t)((clock64() - tl0) >> 4);
+#endif
+        } else {
+            if (wantNode) {
+                cnt.nodes++;
+                count_idle(cnt.idleA);
+#ifdef RT_LOOP_TIMERS
+                if ((int)(threadIdx.x & 63) == __builtin_ctzll(__ballot(true))) cnt.diagA++;
+#endif
+                node_step(s, T.br, T.bound, stack, T.sp, T.node);
+                trav_take_leaf(T, stack);
+            }
+#ifdef RT_LOOP_TIMERS
+            if (leader) cnt.idleA += (uint32_t)((clock64() - tl0) >> 4);
+#endif
+        }
+    }
+}
+
+// Closest hit of a finished traversal; `danger` = another object has a hit inside the tie band.
+__device__ __forceinline__ Hit trav_finish(Trav& T, const SceneView& s, Ray& ray, bool& danger)
+{
+    if (T.best.gid != kNoHit) {
+        const float limit = T.best.t + band_of(T.best.t, T.rayScale);
+        if (T.otherT <= limit) danger = true;
+        cull_lookup(s, ray, T.bestObj, T.cc);
+        if (!object_cull_pass(T.cc.tmin, T.cc.bfar, T.m0)) danger = true;
+        ray.maxDist = T.best.t;
+    }
+    return T.best;
+}
+
 // the reference loop itself with the BVH used for culling only: every object with an accepted hit,
 // in index order (redo launch)
-__device__ __forceinline__ Hit trace_bvh_exact_all(const SceneView& s, Ray& ray, const Stack& stack, BvhCounters& cnt)
+__device__ __forceinline__ Hit trace_bvh_exact_all(const SceneView& s, Ray& ray, Stack& stack, BvhCounters& cnt)
 {
     Hit none; none.t = FLT_MAX; none.gid = kNoHit; none.b0 = none.b1 = none.b2 = 0.0f;
     if (!s.rootIsValid) return none;
