@@ -164,8 +164,12 @@ def test_two_rank_sharding_over_gloo(tmp_path):
     w = tmp_path / "worker.py"
     w.write_text(WORKER)
     env = dict(os.environ, OMP_NUM_THREADS="1")
+    import socket
+    with socket.socket() as sk:  # a free rendezvous port (a fixed one can linger in TIME_WAIT after an earlier run)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29671", str(w), ROOT],
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(w), ROOT],
                        capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "rank 0 ok" in p.stdout and "rank 1 ok" in p.stdout
