@@ -176,7 +176,13 @@ __global__ __launch_bounds__(256) void gather_kernel(const TriIsect* __restrict_
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nTris) return;
     const TriIsect t = triRef[order[j]];
-    triLeaf[j] = t;
+    // three copies, rotated for rays whose dominant axis kz is 0, 1, 2: (x,y,z) -> (kz+1, kz+2, kz) mod 3
+    TriIsect r = t;
+    r.v0x = t.v0y; r.v0y = t.v0z; r.v0z = t.v0x; r.v1x = t.v1y; r.v1y = t.v1z; r.v1z = t.v1x; r.v2x = t.v2y; r.v2y = t.v2z; r.v2z = t.v2x;
+    triLeaf[j] = r;
+    r.v0x = t.v0z; r.v0y = t.v0x; r.v0z = t.v0y; r.v1x = t.v1z; r.v1y = t.v1x; r.v1z = t.v1y; r.v2x = t.v2z; r.v2y = t.v2x; r.v2z = t.v2y;
+    triLeaf[(size_t)nTris + j] = r;
+    triLeaf[2 * (size_t)nTris + j] = t;
     float mn[3], mx[3];
     tri_box(t, mn, mx);
     float* b = boxes + 6 * (size_t)(nTris - 1 + j);
@@ -423,7 +429,7 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
     const uint32_t grid = (nTris + 255) / 256;
 
     RT_HIP(hipMalloc((void**)&out.triRef, sizeof(TriIsect) * (size_t)nTris));
-    RT_HIP(hipMalloc((void**)&out.triLeaf, sizeof(TriIsect) * (size_t)nTris));
+    RT_HIP(hipMalloc((void**)&out.triLeaf, 3 * sizeof(TriIsect) * (size_t)nTris));
     RT_HIP(hipMalloc((void**)&out.triShade, sizeof(TriShade) * (size_t)nTris));
     const uint32_t nInternal = nTris > 1 ? nTris - 1 : 1;
     RT_HIP(hipMalloc((void**)&out.nodes, sizeof(BvhNode) * (size_t)nInternal));

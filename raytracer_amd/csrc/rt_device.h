@@ -12,7 +12,10 @@
 namespace rt {
 
 constexpr uint32_t kNoHit = 0xFFFFFFFFu;
-constexpr int kLeafMax = 4;        // triangles per BVH leaf
+#ifndef RT_LEAF_MAX
+#define RT_LEAF_MAX 2
+#endif
+constexpr int kLeafMax = RT_LEAF_MAX;        // triangles per BVH leaf
 constexpr int kStackDepth = 128;   // exact kernels: up to 3 pushes per level of the four-wide tree
 constexpr int kLdsStack = 32;      // entries per lane kept in LDS; deeper entries spill to scratch
 constexpr int kBlock = 256;        // workgroup size of every tracing kernel
@@ -85,7 +88,8 @@ static_assert(sizeof(BvhNode) == 64, "BvhNode layout");
 
 struct SceneView {
     const TriIsect* triRef;    // [nTris] reference order
-    const TriIsect* triLeaf;   // [nTris] BVH leaf order
+    const TriIsect* triLeaf;   // [3][nTris] BVH leaf order; copy k holds the coordinates rotated for rays whose
+                               // dominant direction axis is k: (x,y,z) -> (k+1, k+2, k) mod 3
     const TriShade* triShade;  // [nTris] reference order
     const ObjCull* objects;    // [nObjects]
     const DevMaterial* materials;

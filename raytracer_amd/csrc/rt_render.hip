@@ -205,8 +205,7 @@ __device__ __forceinline__ Surface shade_surface(const SceneView& s, const Hit& 
     const float u = u0 * h.b0 + u1 * h.b1 + u2 * h.b2;
     const float v = w0 * h.b0 + w1 * h.b1 + w2 * h.b2;
 
-    o.albedo = m.texAlbedo < 0 ? mk4(m.albedo[0], m.albedo[1], m.albedo[2], m.albedo[3])
-                               : tex2d_norm(s.textures[m.texAlbedo], u, v);
+    o.albedo = m.texAlbedo < 0 ? mk4(m.albedo[0], m.albedo[1], m.albedo[2], m.albedo[3]) : tex2d_norm(s.textures[m.texAlbedo], u, v);
     V4 nl;
     if (m.texNormal < 0) nl = mk4(0.0f, 0.0f, 1.0f, 0.0f);
     else {
@@ -260,8 +259,12 @@ struct PathAcc {
 
 // One iteration of the bounce loop (:172-242) after the closest-hit query.  Returns true when
 // the path continues with the updated ray.
+// cullObj != kNoHit: the closest-hit query skipped the object-space cull of the winner's object
+// (hot kernel); it is evaluated here, its 96-byte fetch riding with the triangle records, and a
+// failure is reported through cullFail (the pixel then goes to the redo launch).
 __device__ __forceinline__ bool shade_segment(const RenderArgs& a, const Hit& h, Ray& ray, uint32_t& seed, uint32_t sample,
-                                              int i, PathAcc& p, LaneStats& st, uint32_t& checksum, uint32_t* primary)
+                                              int i, PathAcc& p, LaneStats& st, uint32_t& checksum, uint32_t* primary,
+                                              uint32_t cullObj = kNoHit, float cullMax = 0.0f, bool* cullFail = nullptr)
 {
     if (h.gid == kNoHit) {
         checksum += seg_hash(kNoHit, kNoHit, kNoHit, sample, (uint32_t)i);
@@ -274,6 +277,12 @@ __device__ __forceinline__ bool shade_segment(const RenderArgs& a, const Hit& h,
     }
     uint32_t ho, hm, ht;
     st.hits++;
+    if (cullObj != kNoHit) {
+        const ObjCull o = load_obj(a.scene.objects + cullObj);
+        float tmin, bfar;
+        object_slab(ray, o, tmin, bfar);
+        if (!object_cull_pass(tmin, bfar, cullMax)) *cullFail = true;
+    }
     const Surface sf = shade_surface(a.scene, h, ho, hm, ht);
     checksum += seg_hash(ho, hm, ht, sample, (uint32_t)i);
     if (i == 0 && sample == 0) { primary[0] = ho; primary[1] = hm; primary[2] = ht; }
@@ -380,6 +389,9 @@ __device__ __forceinline__ void flush_stats(const RenderArgs& a, const LaneStats
 #ifdef RT_LOOP_TIMERS
     v1 = st.bvh.diagA; v4 = st.bvh.diagB; // diagnostic build: wave-level loop iterations replace slow-path rays / hits
 #endif
+#ifdef RT_PHASE_TIMERS
+    v3 = st.bvh.diagA; v4 = st.bvh.diagB; // diagnostic build: pool / raygen cycles replace tri tests / hits
+#endif
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         v5 += __shfl_xor(v5, off); v6 += __shfl_xor(v6, off);
@@ -427,7 +439,10 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
 // Traversal therefore always runs with most lanes busy, whatever the path lengths and however
 // uneven the rays; in the reference (and in the tile kernel below) a wave pays for its longest
 // path and its longest ray while the other lanes sit idle.
-constexpr int kKeepNum = 3, kKeepDen = 8;
+#ifndef RT_KEEP_NUM
+#define RT_KEEP_NUM 2
+#endif
+constexpr int kKeepNum = RT_KEEP_NUM, kKeepDen = 8;
 
 __global__ __launch_bounds__(256, 3) void path_kernel(const RenderArgs a)
 {
@@ -470,9 +485,9 @@ __global__ __launch_bounds__(256, 3) void path_kernel(const RenderArgs a)
         if (hasPath && !trav_running(T)) {
             bool danger = false;
             const Hit h = trav_finish(T, a.scene, ray, danger);
-            if (danger) { flagged = true; st.slow++; }
             if (stack.dropped) { flagged = true; stack.dropped = false; } // stack overflow: the redo launch has the deep stack
             const uint32_t sidx = iter * 4u + z;
+            if (danger) { flagged = true; st.slow++; }
             const bool more = shade_segment(a, h, ray, seed, sidx, bounce, acc, st, checksum, primary);
             bounce++;
             if (more) {
@@ -486,6 +501,10 @@ __global__ __launch_bounds__(256, 3) void path_kernel(const RenderArgs a)
                 pb += 1.0f - rtd::exp_f(-acc.oz * a.exposure);
             }
         }
+#ifdef RT_PHASE_TIMERS
+        const long long tpa = clock64();
+        const int nShade = __popcll(__ballot(true));
+#endif
         // ---- (1a) lanes whose path ended: next sample of the pixel, or the pixel is finished
         if (hasPixel && !hasPath) {
             iter++;
@@ -554,6 +573,9 @@ __global__ __launch_bounds__(256, 3) void path_kernel(const RenderArgs a)
             poolMask = m;
             need = __ballot(!hasPixel && !noMore);
         }
+#ifdef RT_PHASE_TIMERS
+        const long long tpc = clock64();
+#endif
         // ---- (1c) start the next sample
         if (hasPixel && !hasPath) {
             const uint32_t sidx = iter * 4u + z;
@@ -582,7 +604,12 @@ __global__ __launch_bounds__(256, 3) void path_kernel(const RenderArgs a)
         if (running) trav_burst(T, a.scene, ray, stack, st.bvh, (nRun * kKeepNum + kKeepDen - 1) / kKeepDen);
 #ifdef RT_PHASE_TIMERS
         // diagnostic build: wave cycles outside / inside the traversal burst (reported through the idle-lane slots, /64)
-        if (lane == 0) { st.bvh.idleB += (uint32_t)((tp1 - tp0) >> 6); st.bvh.idleA += (uint32_t)((clock64() - tp1) >> 6); }
+        // slots: idleA burst, idleB shade, diagA pool, diagB raygen (all /64); slow = main-loop iterations
+        if (lane == 0) {
+            st.bvh.idleA += (uint32_t)((clock64() - tp1) >> 6); st.bvh.idleB += (uint32_t)((tpa - tp0) >> 6);
+            st.bvh.diagA += (uint32_t)((tpc - tpa) >> 6); st.bvh.diagB += (uint32_t)((tp1 - tpc) >> 6);
+            st.slow++;
+        }
 #endif
     }
     flush_stats(a, st, wgCnt);

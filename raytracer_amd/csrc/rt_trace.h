@@ -35,6 +35,7 @@ struct Hit {
 struct TriRay {
     int kz;
     float sx, sy, sz;
+    float pox, poy, poz;   // origin in the rotated frame (kx, ky, kz)
 };
 
 __device__ __forceinline__ float sel3(int k, float a, float b, float c) { return k == 0 ? a : (k == 1 ? b : c); }
@@ -51,24 +52,19 @@ __device__ __forceinline__ TriRay make_tri_ray(const Ray& r)
     q.sz = 1.f / dZ;
     q.sx = -dX * q.sz;
     q.sy = -dY * q.sz;
+    q.pox = sel3(q.kz, r.oy, r.oz, r.ox);
+    q.poy = sel3(q.kz, r.oz, r.ox, r.oy);
+    q.poz = sel3(q.kz, r.ox, r.oy, r.oz);
     return q;
 }
 
 // :551-637.  Returns true and fills t / barycentrics when the triangle is hit within
 // (0.001, maxDist]; bit-for-bit the oracle's dist_to_triangle.
-__device__ __forceinline__ bool tri_test(const Ray& r, const TriRay& q, float maxDist,
-                                         float v0x, float v0y, float v0z, float v1x, float v1y, float v1z,
-                                         float v2x, float v2y, float v2z, float& tOut, float& b0Out,
-                                         float& b1Out, float& b2Out)
+// core of the test on vertices already translated to the ray origin and rotated into (kx, ky, kz)
+__device__ __forceinline__ bool tri_test_core(const TriRay& q, float maxDist, float p0x, float p0y, float p0z, float p1x,
+                                              float p1y, float p1z, float p2x, float p2y, float p2z, float& tOut,
+                                              float& b0Out, float& b1Out, float& b2Out)
 {
-    const float a0x = v0x - r.ox, a0y = v0y - r.oy, a0z = v0z - r.oz;
-    const float a1x = v1x - r.ox, a1y = v1y - r.oy, a1z = v1z - r.oz;
-    const float a2x = v2x - r.ox, a2y = v2y - r.oy, a2z = v2z - r.oz;
-
-    float p0x = sel3(q.kz, a0y, a0z, a0x), p0y = sel3(q.kz, a0z, a0x, a0y), p0z = sel3(q.kz, a0x, a0y, a0z);
-    float p1x = sel3(q.kz, a1y, a1z, a1x), p1y = sel3(q.kz, a1z, a1x, a1y), p1z = sel3(q.kz, a1x, a1y, a1z);
-    float p2x = sel3(q.kz, a2y, a2z, a2x), p2y = sel3(q.kz, a2z, a2x, a2y), p2z = sel3(q.kz, a2x, a2y, a2z);
-
     p0x += q.sx * p0z; p0y += q.sy * p0z;
     p1x += q.sx * p1z; p1y += q.sy * p1z;
     p2x += q.sx * p2z; p2y += q.sy * p2z;
@@ -102,6 +98,30 @@ __device__ __forceinline__ bool tri_test(const Ray& r, const TriRay& q, float ma
 
     tOut = t; b0Out = e0 * invDet; b1Out = e1 * invDet; b2Out = e2 * invDet;
     return true;
+}
+
+// world-space vertices (reference order records, brute force)
+__device__ __forceinline__ bool tri_test(const Ray& r, const TriRay& q, float maxDist,
+                                         float v0x, float v0y, float v0z, float v1x, float v1y, float v1z,
+                                         float v2x, float v2y, float v2z, float& tOut, float& b0Out,
+                                         float& b1Out, float& b2Out)
+{
+    const float a0x = v0x - r.ox, a0y = v0y - r.oy, a0z = v0z - r.oz;
+    const float a1x = v1x - r.ox, a1y = v1y - r.oy, a1z = v1z - r.oz;
+    const float a2x = v2x - r.ox, a2y = v2y - r.oy, a2z = v2z - r.oz;
+    return tri_test_core(q, maxDist, sel3(q.kz, a0y, a0z, a0x), sel3(q.kz, a0z, a0x, a0y), sel3(q.kz, a0x, a0y, a0z),
+                         sel3(q.kz, a1y, a1z, a1x), sel3(q.kz, a1z, a1x, a1y), sel3(q.kz, a1x, a1y, a1z),
+                         sel3(q.kz, a2y, a2z, a2x), sel3(q.kz, a2z, a2x, a2y), sel3(q.kz, a2x, a2y, a2z), tOut, b0Out,
+                         b1Out, b2Out);
+}
+
+// vertices from the leaf-order copy already rotated for this ray's kz (SceneView::triLeaf): the same
+// subtractions on the same operands as above, without the 18 three-way selects per triangle
+__device__ __forceinline__ bool tri_test_rot(const TriRay& q, float maxDist, const float4& A, const float4& B,
+                                             const float4& C, float& tOut, float& b0Out, float& b1Out, float& b2Out)
+{
+    return tri_test_core(q, maxDist, A.x - q.pox, A.y - q.poy, A.z - q.poz, B.x - q.pox, B.y - q.poy, B.z - q.poz,
+                         C.x - q.pox, C.y - q.poy, C.z - q.poz, tOut, b0Out, b1Out, b2Out);
 }
 
 // :728-743 (transpose == false), columns c0..c3 of a column-major 16-float matrix
@@ -366,7 +386,7 @@ __device__ __forceinline__ void node_step(const SceneView& s, const BoxRay& br, 
 }
 
 template <class STACK, class Visit>
-__device__ __forceinline__ void bvh_walk(const SceneView& s, const BoxRay& br, float bound, STACK& stack,
+__device__ __forceinline__ void bvh_walk(const SceneView& s, const BoxRay& br, const TriRay& q, float bound, STACK& stack,
                                          BvhCounters& cnt, Visit&& visit)
 {
     if (!s.rootIsValid) return;
@@ -389,7 +409,7 @@ __device__ __forceinline__ void bvh_walk(const SceneView& s, const BoxRay& br, f
             const uint32_t code = (uint32_t)(~leaf);
             const uint32_t first = code >> 3, count = code & 7u;
             for (uint32_t k = 0; k < count; k++) {
-                const float4* p = reinterpret_cast<const float4*>(s.triLeaf + first + k);
+                const float4* p = reinterpret_cast<const float4*>(s.triLeaf + (size_t)q.kz * s.nTris + first + k);
                 const float4 A = p[0], B = p[1], C = p[2];
                 cnt.tris++;
                 count_idle(cnt.idleB);
@@ -431,11 +451,11 @@ __device__ __noinline__ Hit trace_bvh_exact(const SceneView& s, Ray& ray, const 
         // next object id after `prev` that has an accepted hit within the limit
         uint32_t next = kNoHit;
         CullCache cc; cc.obj = kNoHit; cc.tmin = 0.0f; cc.bfar = 0.0f;
-        bvh_walk(s, br, limit, stack, cnt, [&](const float4& A, const float4& B, const float4& C, float bound) {
+        bvh_walk(s, br, q, limit, stack, cnt, [&](const float4& A, const float4& B, const float4& C, float bound) {
             const uint32_t obj = __float_as_uint(B.w);
             if ((prev == kNoHit || obj > prev) && obj < next) {
                 float t, b0, b1, b2;
-                if (tri_test(ray, q, m0, A.x, A.y, A.z, B.x, B.y, B.z, C.x, C.y, C.z, t, b0, b1, b2) && t <= limit) {
+                if (tri_test_rot(q, m0, A, B, C, t, b0, b1, b2) && t <= limit) {
                     cull_lookup(s, ray, obj, cc);
                     if (object_cull_pass(cc.tmin, cc.bfar, m0)) next = obj;
                 }
@@ -448,10 +468,10 @@ __device__ __noinline__ Hit trace_bvh_exact(const SceneView& s, Ray& ray, const 
         if (!object_cull_pass(cc.tmin, cc.bfar, m)) continue;
         // closest hit inside that object with ray.maxDistance = m
         Hit ob; ob.t = FLT_MAX; ob.gid = kNoHit; ob.b0 = ob.b1 = ob.b2 = 0.0f;
-        bvh_walk(s, br, m, stack, cnt, [&](const float4& A, const float4& B, const float4& C, float bound) {
+        bvh_walk(s, br, q, m, stack, cnt, [&](const float4& A, const float4& B, const float4& C, float bound) {
             if (__float_as_uint(B.w) == next) {
                 float t, b0, b1, b2;
-                if (tri_test(ray, q, m, A.x, A.y, A.z, B.x, B.y, B.z, C.x, C.y, C.z, t, b0, b1, b2)) {
+                if (tri_test_rot(q, m, A, B, C, t, b0, b1, b2)) {
                     const uint32_t gid = __float_as_uint(A.w);
                     if (t < ob.t || (t == ob.t && gid < ob.gid)) {
                         ob.t = t; ob.b0 = b0; ob.b1 = b1; ob.b2 = b2; ob.gid = gid;
@@ -487,9 +507,9 @@ __device__ __forceinline__ Hit trace_bvh(const SceneView& s, Ray& ray, Stack& st
     float otherT = FLT_MAX; // closest accepted hit on an object other than best's
     CullCache cc; cc.obj = kNoHit; cc.tmin = 0.0f; cc.bfar = 0.0f;
 
-    bvh_walk(s, br, m0, stack, cnt, [&](const float4& A, const float4& B, const float4& C, float bound) {
+    bvh_walk(s, br, q, m0, stack, cnt, [&](const float4& A, const float4& B, const float4& C, float bound) {
         float t, b0, b1, b2;
-        if (!tri_test(ray, q, m0, A.x, A.y, A.z, B.x, B.y, B.z, C.x, C.y, C.z, t, b0, b1, b2)) return bound;
+        if (!tri_test_rot(q, m0, A, B, C, t, b0, b1, b2)) return bound;
         if (t > bound) return bound;
         const uint32_t gid = __float_as_uint(A.w), obj = __float_as_uint(B.w);
         cull_lookup(s, ray, obj, cc);
@@ -529,7 +549,7 @@ __device__ __forceinline__ Hit trace_bvh(const SceneView& s, Ray& ray, Stack& st
 // triangle-loop iteration ran with 16-25 of 64 lanes and a node-loop iteration with 25-33.
 struct Trav {
     int32_t node;
-    uint32_t triFirst, triCount;
+    uint32_t triFirst, triCount, triBase;
     int sp;
     float bound, m0, rayScale;
     Hit best;
@@ -549,18 +569,18 @@ __device__ __forceinline__ void trav_begin(Trav& T, const SceneView& s, const Ra
     T.best.t = FLT_MAX; T.best.gid = kNoHit; T.best.b0 = T.best.b1 = T.best.b2 = 0.0f;
     T.bestObj = kNoHit; T.otherT = FLT_MAX;
     T.cc.obj = kNoHit; T.cc.tmin = 0.0f; T.cc.bfar = 0.0f;
-    stack.reset(T.sp); T.triFirst = 0; T.triCount = 0;
+    stack.reset(T.sp); T.triFirst = 0; T.triCount = 0; T.triBase = (uint32_t)T.q.kz * s.nTris;
     T.node = s.rootIsValid ? 0 : kTravEnd;
 }
 
 __device__ __forceinline__ bool trav_running(const Trav& T) { return T.node != kTravEnd || T.triCount != 0u; }
 
 // a leaf in `node` becomes the pending triangle range once the previous range is used up
-__device__ __forceinline__ void trav_take_leaf(Trav& T, HotStack& stack)
+__device__ __forceinline__ void trav_take_leaf(Trav& T, const SceneView& s, HotStack& stack)
 {
     if (T.triCount == 0u && T.node < 0) {
         const uint32_t code = (uint32_t)(~T.node);
-        T.triFirst = code >> 3; T.triCount = code & 7u;
+        T.triFirst = (code >> 3) + T.triBase; T.triCount = code & 7u;
         T.node = (int32_t)stack.pop(T.sp);
     }
 }
@@ -576,7 +596,7 @@ __device__ __forceinline__ void trav_tri_step(Trav& T, const SceneView& s, const
         // The object-space cull of the winner's object (GPURaytracer.cu:267-315) is checked once, in
         // trav_finish: a hit on an object whose cull fails (flat meshes) sends the pixel to
         // the redo launch instead of costing every triangle step a 96-byte fetch and a slab test.
-        if (tri_test(ray, T.q, T.m0, A.x, A.y, A.z, B.x, B.y, B.z, C.x, C.y, C.z, t, b0, b1, b2) && t <= T.bound) {
+        if (tri_test_rot(T.q, T.m0, A, B, C, t, b0, b1, b2) && t <= T.bound) {
             const uint32_t gid = __float_as_uint(A.w), obj = __float_as_uint(B.w);
             const bool better = t < T.best.t || (t == T.best.t && gid < T.best.gid);
             if (obj != T.bestObj) {
@@ -589,7 +609,7 @@ __device__ __forceinline__ void trav_tri_step(Trav& T, const SceneView& s, const
             }
         }
     }
-    trav_take_leaf(T, stack);
+    trav_take_leaf(T, s, stack);
 }
 
 #ifndef RT_TRI_NUM
@@ -632,7 +652,7 @@ __device__ __forceinline__ void trav_burst(Trav& T, const SceneView& s, const Ra
                 if ((int)(threadIdx.x & 63) == __builtin_ctzll(__ballot(true))) cnt.diagA++;
 #endif
                 node_step(s, T.br, T.bound, stack, T.sp, T.node);
-                trav_take_leaf(T, stack);
+                trav_take_leaf(T, s, stack);
             }
 #ifdef RT_LOOP_TIMERS
             if (leader) cnt.idleA += (uint32_t)((clock64() - tl0) >> 4);
