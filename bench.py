@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--cpu-crop", type=int, default=192, help="side of the centred crop the CPU baseline renders")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--brute", action="store_true", help="reference-order brute force instead of the BVH")
+    ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "persistent"],
+                    help="BVH render pipeline: per-bounce trace/shade launches (default) or the single persistent kernel")
+    ap.add_argument("--wf-chunk", type=int, default=0, help="samples in flight per chunk of the wavefront pipeline (0 = library default)")
     args = ap.parse_args()
 
     import torch
@@ -90,7 +93,9 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
-    ctx.set_option(capi.OPT_TRAVERSAL, 1 if args.brute else 0)
+    ctx.set_option(capi.OPT_TRAVERSAL, 1 if args.brute else (0 if args.pipeline == "wavefront" else 2))
+    if args.wf_chunk:
+        ctx.set_option(capi.OPT_WF_CHUNK, args.wf_chunk)
     t0 = time.time()
     ctx.upload_scene(flat)
     upload_s = time.time() - t0
@@ -191,7 +196,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": label, "width": W, "height": H, "spp": int(st.sampleCount),
                        "depth": int(st.bounceCount), "triangles": int(s.triangles), "objects": len(flat.objects),
-                       "mode": args.mode, "traversal": "brute" if args.brute else "bvh",
+                       "mode": args.mode, "traversal": "brute" if args.brute else "bvh", "pipeline": args.pipeline,
                        "rays_per_frame": rays_local / args.steps, "scene_upload_s": upload_s,
                        "bvh_build_ms": float(s.commit_ms)},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -88,9 +88,12 @@ typedef struct {
 } rt_stats;
 
 enum rt_option {
-    RT_OPT_TRAVERSAL = 1, /* 0 = BVH (default), 1 = brute force in reference order */
+    RT_OPT_TRAVERSAL = 1, /* 0 = BVH, wavefront pipeline (default); 1 = brute force in reference order;
+                             2 = BVH, single persistent kernel.  All three give the same pixels. */
     RT_OPT_COUNTERS = 2,  /* reserved */
-    RT_OPT_ACCUMULATE_STATS = 3 /* 1 = rt_render no longer zeroes the counters; setting it zeroes them once */
+    RT_OPT_ACCUMULATE_STATS = 3, /* 1 = rt_render no longer zeroes the counters; setting it zeroes them once */
+    RT_OPT_WF_CHUNK = 4   /* samples in flight per chunk of the wavefront pipeline (0 = default, 64 Mi); the
+                             workspace holds ~113 bytes per sample */
 };
 
 /* ---- context ---- */

@@ -11,6 +11,7 @@
 namespace {
 
 constexpr size_t kWorkBytes = sizeof(uint32_t) * 512;
+constexpr size_t kWfChunkDefault = 64u << 20;
 constexpr size_t kCntBytes = sizeof(unsigned long long) * rt::kCounterSlots * rt::kCounterStride;
 
 thread_local std::string g_createError;
@@ -59,6 +60,8 @@ struct rt_ctx {
     bool renderedOnce = false;
     float commitMs = 0.0f;
     int optTraversal = 0;
+    size_t optWfChunk = kWfChunkDefault;     // samples in flight per chunk of the wavefront pipeline
+    rt::WfBufs wf{}; size_t wfCapSlots = 0; int wfLevels = 0;   // its workspace, grown on demand
     int optCounters = 0;
     int optAccumulate = 0;
     int numCUs = 256;
@@ -115,6 +118,41 @@ int check_material_desc(rt_ctx* c, const rt_material_desc* d)
     for (int i = 0; i < 4; i++)
         if (t[i] != -1 && !valid(c->textures, t[i])) return fail(c, RT_ERR_INVALID, "material references an invalid texture handle");
     return RT_OK;
+}
+
+void free_wf(rt_ctx* c)
+{
+    hipFree(c->wf.rayO); hipFree(c->wf.rayD); hipFree(c->wf.hitA); hipFree(c->wf.hitG); hipFree(c->wf.accO); hipFree(c->wf.accB);
+    hipFree(c->wf.out); hipFree(c->wf.outRays); hipFree(c->wf.pixFlag); hipFree(c->wf.queue); hipFree(c->wf.ctrl);
+    c->wf = rt::WfBufs{}; c->wfCapSlots = 0; c->wfLevels = 0;
+}
+
+// workspace of the wavefront pipeline: ~113 bytes per sample in flight
+hipError_t ensure_wf(rt_ctx* c, size_t slots, int levels)
+{
+    if (slots <= c->wfCapSlots && levels <= c->wfLevels) return hipSuccess;
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return e;
+    if (slots < c->wfCapSlots) slots = c->wfCapSlots;
+    if (levels < c->wfLevels) levels = c->wfLevels;
+    free_wf(c);
+    rt::WfBufs& w = c->wf;
+    const size_t pieces = (slots + 255) / 256;
+    w.subCap = (uint32_t)(((pieces + rt::kWfStripes - 1) / rt::kWfStripes) * 256);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.rayO, 16 * slots);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.rayD, 16 * slots);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.hitA, 16 * slots);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.hitG, 4 * slots);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.accO, 16 * slots);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.accB, 16 * slots);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.out, 16 * slots);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.outRays, slots);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.pixFlag, 4 * slots);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.queue, sizeof(uint32_t) * 2 * rt::kWfStripes * (size_t)w.subCap);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.ctrl, sizeof(uint32_t) * (size_t)(levels + 1) * 2 * rt::kWfStripes * rt::kWfCtrlStride);
+    if (e != hipSuccess) { free_wf(c); return e; }
+    c->wfCapSlots = slots; c->wfLevels = levels;
+    return hipSuccess;
 }
 
 rt::SceneView scene_view(const rt_ctx* c)
@@ -211,6 +249,7 @@ int rt_ctx_destroy(rt_ctx* c)
     for (auto& f : c->fbs) if (f.live) { if (f.owned) hipFree(f.data); hipFree(f.ids); }
     rt::free_scene(c->built);
     hipFree(c->dObjects); hipFree(c->dMaterials); hipFree(c->dTextures); hipFree(c->dRays); hipFree(c->dCounters); hipFree(c->dWork); hipFree(c->dRedoList);
+    free_wf(c);
     if (c->hCounters) hipHostFree(c->hCounters);
     if (c->evBegin) hipEventDestroy(c->evBegin);
     if (c->evEnd) hipEventDestroy(c->evEnd);
@@ -232,8 +271,12 @@ int rt_set_option(rt_ctx* c, int option, int value)
     RT_BIND(c);
     switch (option) {
     case RT_OPT_TRAVERSAL:
-        if (value != 0 && value != 1) return fail(c, RT_ERR_INVALID, "RT_OPT_TRAVERSAL takes 0 (BVH) or 1 (brute force)");
+        if (value < 0 || value > 2)
+            return fail(c, RT_ERR_INVALID, "RT_OPT_TRAVERSAL takes 0 (BVH, wavefront pipeline), 1 (brute force) or 2 (BVH, single persistent kernel)");
         c->optTraversal = value; return RT_OK;
+    case RT_OPT_WF_CHUNK:
+        if (value < 0) return fail(c, RT_ERR_INVALID, "RT_OPT_WF_CHUNK takes a sample count >= 0 (0 = default)");
+        c->optWfChunk = value ? (size_t)value : kWfChunkDefault; return RT_OK;
     case RT_OPT_COUNTERS: c->optCounters = value ? 1 : 0; return RT_OK;
     case RT_OPT_ACCUMULATE_STATS:
         c->optAccumulate = value ? 1 : 0;
@@ -636,7 +679,24 @@ int rt_render(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* 
 
     if (!c->optAccumulate) RT_CHECK(c, hipMemsetAsync(c->dCounters, 0, kCntBytes, c->stream));
     RT_CHECK(c, hipEventRecord(c->evBegin, c->stream));
-    rt::launch_render(a, c->optTraversal, c->numCUs, c->stream);
+    // mode 0: wavefront pipeline (the single persistent kernel, mode 2, remains for very deep paths:
+    // the per-sample query count of the pipeline is a byte)
+    if (c->optTraversal == 0 && rnd->bounceCount <= 200) {
+        const size_t tiles = (size_t)((tile.x1 - tile.x0 + 7) / 8) * (size_t)((tile.y1 - tile.y0 + 7) / 8);
+        const size_t perTile = 64 * (size_t)rnd->sampleCount;
+        size_t chunkTiles = c->optWfChunk / perTile;
+        if (chunkTiles == 0) chunkTiles = 1;
+        if (chunkTiles > tiles) chunkTiles = tiles;
+        if (chunkTiles * perTile >= (1ull << 31)) return fail(c, RT_ERR_INVALID, "sampleCount too large for one 8x8 tile of the wavefront workspace");
+        if (tiles > 0) {
+            hipError_t e = ensure_wf(c, chunkTiles * perTile, rnd->bounceCount > 0 ? rnd->bounceCount : 0);
+            if (e != hipSuccess) return fail(c, RT_ERR_HIP, std::string("wavefront workspace: ") + hipGetErrorString(e));
+            RT_CHECK(c, hipEventRecord(c->evBegin, c->stream));
+            rt::launch_render_wf(a, c->wf, (uint32_t)c->wfCapSlots, c->numCUs, c->stream);
+        }
+    } else {
+        rt::launch_render(a, c->optTraversal == 1 ? 1 : 0, c->numCUs, c->stream);
+    }
     RT_CHECK(c, hipGetLastError());
     RT_CHECK(c, hipEventRecord(c->evEnd, c->stream));
     c->renderedOnce = true;

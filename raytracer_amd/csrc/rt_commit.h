@@ -37,6 +37,7 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
 void free_scene(BuiltScene& s);
 
 void launch_render(const RenderArgs& a, int mode, int numCUs, hipStream_t stream);
+void launch_render_wf(const RenderArgs& a, const WfBufs& proto, uint32_t capSlots, int numCUs, hipStream_t stream);
 void launch_trace_rays(const SceneView& s, const float4* rays, int n, uint4* out, unsigned long long* counters, int mode,
                        hipStream_t stream);
 void launch_detmath(int op, const float* in, int n, float* out, hipStream_t stream);

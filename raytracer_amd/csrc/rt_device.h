@@ -18,6 +18,10 @@ constexpr uint32_t kNoHit = 0xFFFFFFFFu;
 constexpr int kLeafMax = RT_LEAF_MAX;        // triangles per BVH leaf
 constexpr int kStackDepth = 128;   // exact kernels: up to 3 pushes per level of the four-wide tree
 constexpr int kLdsStack = 32;      // entries per lane kept in LDS; deeper entries spill to scratch
+#ifndef RT_WF_STACK
+#define RT_WF_STACK 32
+#endif
+constexpr int kWfStack = RT_WF_STACK; // LDS stack entries per lane in wf_trace (overflow -> redo): 32 KB per workgroup
 constexpr int kBlock = 256;        // workgroup size of every tracing kernel
 constexpr int kCounterSlots = 256; // statistics counters are striped over this many 128-byte lines
 constexpr int kCounterStride = 16; // u64 per slot
@@ -99,6 +103,34 @@ struct SceneView {
     uint32_t nObjects;
     int32_t rootIsValid;       // 0 when the scene holds no triangle
     float sceneMaxAbs;         // max |coordinate| over all world-space vertices
+};
+
+// ---- wavefront pipeline (rt_render.hip, "wf_" kernels) ----
+// One slot per sample of a chunk of 8x8 pixel tiles: slot = pixelInChunk * spp + sampleIndex.
+// Per bounce level L a queue lists the slots whose path is still alive; it is cut into kWfStripes
+// sub-queues with their own counts and cursors (a single hot counter saturates at ~88 atomics/us).
+constexpr int kWfStripes = 64;
+constexpr int kWfCtrlStride = 32;          // words between two counters (one 128-byte line each)
+constexpr uint32_t kWfHole = 0xFFFFFFFFu;  // queue entry without a path
+constexpr uint32_t kWfMiss = 0x0FFFFFFFu;  // hitG: no triangle
+constexpr uint32_t kWfDanger = 0x80000000u; // hitG flag: the pixel must be re-rendered by the exact kernel
+
+struct WfBufs {
+    float4* rayO;        // [slot] origin, maxDistance
+    float4* rayD;        // [slot] direction, RNG state
+    float4* hitA;        // [slot] t, b0, b1, b2 of the closest hit
+    uint32_t* hitG;      // [slot] gid | flags
+    float4* accO;        // [slot] outgoing light, checksum bits
+    float4* accB;        // [slot] beta accumulation
+    float4* out;         // [slot] finished sample: exposure-corrected rgb, checksum bits
+    uint8_t* outRays;    // [slot] closest-hit queries of the finished sample
+    uint32_t* pixFlag;   // [pixelInChunk] != 0: flagged for the redo launch
+    uint32_t* queue;     // [2][kWfStripes][subCap] slots, ping-pong over levels
+    uint32_t* ctrl;      // [level][2][kWfStripes][kWfCtrlStride]: counts, cursors
+    uint32_t subCap;
+    uint32_t nSlots;
+    uint32_t nPix;       // pixels of the chunk = tiles * 64 (edge tiles include pixels outside the rectangle)
+    uint32_t tileBegin;  // first tile of the chunk (tile index over the render rectangle, row-major)
 };
 
 struct RenderArgs {

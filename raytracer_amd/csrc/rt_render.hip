@@ -375,7 +375,10 @@ __device__ __forceinline__ void write_pixel(const RenderArgs& a, int x, int y, f
         b = (b + prev.z * n) / n1;
     }
     a.fb[pix] = make_float4(r, g, b, 1.0f);
-    if (a.ids) a.ids[pix] = make_uint4(primary[0], primary[1], primary[2], checksum);
+    if (a.ids) {
+        if (primary) a.ids[pix] = make_uint4(primary[0], primary[1], primary[2], checksum);
+        else reinterpret_cast<uint32_t*>(a.ids + pix)[3] = checksum; // wavefront pipeline: wf_shade wrote the ids
+    }
 }
 
 // statistics: wave shuffle -> LDS -> one global atomic per workgroup and counter, striped over
@@ -736,6 +739,255 @@ __global__ __launch_bounds__(256) void trace_rays_kernel(SceneView s, const floa
     if (st.slow) atomicAdd(counters + 1, (unsigned long long)st.slow);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wavefront pipeline.  The persistent path kernel above keeps a lane's whole path in registers, so
+// the traversal loops run at the occupancy the shading code's registers allow (168 VGPRs, 3 waves
+// per SIMD) and the shading code runs behind the traversal's live state; measured, both halves were
+// bound by the latency of dependent fetches at that occupancy.  Here the path state lives in HBM
+// (288 GB: 100 bytes per sample in flight is nothing) and each bounce level is two launches:
+//   wf_trace: persistent, closest-hit queries only, lanes refilled from the level's queue;
+//   wf_shade: one lane per live path, full waves, material fetches batched.
+// The per-sample results are summed per pixel in the reference's order by wf_resolve.
+__device__ __forceinline__ uint32_t* wf_count(const WfBufs& w, int level, int stripe)
+{
+    return w.ctrl + ((size_t)(level * 2 + 0) * kWfStripes + stripe) * kWfCtrlStride;
+}
+__device__ __forceinline__ uint32_t* wf_cursor(const WfBufs& w, int level, int stripe)
+{
+    return w.ctrl + ((size_t)(level * 2 + 1) * kWfStripes + stripe) * kWfCtrlStride;
+}
+__device__ __forceinline__ uint32_t* wf_queue(const WfBufs& w, int level, int stripe)
+{
+    return w.queue + ((size_t)(level & 1) * kWfStripes + stripe) * (size_t)w.subCap;
+}
+// slot -> pixel; false when the pixel lies outside the render rectangle (edge tiles)
+__device__ __forceinline__ bool wf_pixel(const RenderArgs& a, const WfBufs& w, uint32_t pix, int& x, int& y)
+{
+    const uint32_t tile = w.tileBegin + (pix >> 6), in = pix & 63u;
+    x = a.x0 + (int)(tile % (uint32_t)a.tiles8X) * 8 + (int)(in & 7u);
+    y = a.y0 + (int)(tile / (uint32_t)a.tiles8X) * 8 + (int)(in >> 3);
+    return x < a.x1 && y < a.y1;
+}
+
+// level 0: camera rays (:140-163), path state, queue 0 (identity order, holes for pixels outside)
+__global__ __launch_bounds__(256) void wf_gen_kernel(const RenderArgs a, const WfBufs w)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t nPieces = (w.nSlots + 255u) / 256u;
+    if (blockIdx.x == 0 && threadIdx.x < kWfStripes) {
+        const uint32_t s = threadIdx.x;
+        const uint32_t pieces = s < nPieces ? (nPieces - s + kWfStripes - 1) / kWfStripes : 0u;
+        *wf_count(w, 0, (int)s) = pieces * 256u;
+    }
+    const uint32_t piece = blockIdx.x, stripe = piece % kWfStripes, off = (piece / kWfStripes) * 256u + threadIdx.x;
+    uint32_t entry = kWfHole;
+    if (i < w.nSlots) {
+        const uint32_t spp = a.sampleCount;
+        const uint32_t pix = i / spp, sidx = i - pix * spp;
+        int x, y;
+        if (wf_pixel(a, w, pix, x, y)) {
+            if (sidx == 0) w.pixFlag[pix] = 0u;
+            uint32_t seed = sample_seed(a, x, y, sidx);
+            const Ray ray = setup_ray(a, x, y, seed);
+            if (a.bounceCount > 0) {
+                w.rayO[i] = make_float4(ray.ox, ray.oy, ray.oz, ray.maxDist);
+                w.rayD[i] = make_float4(ray.dx, ray.dy, ray.dz, __uint_as_float(seed));
+                w.accO[i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
+                w.accB[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+                entry = i;
+            } else { // the bounce loop does not run: radiance 0 (:172)
+                if (sidx == 0 && a.ids) {
+                    uint32_t* idp = reinterpret_cast<uint32_t*>(a.ids + ((size_t)y * (size_t)a.width + (size_t)x));
+                    idp[0] = kNoHit; idp[1] = kNoHit; idp[2] = kNoHit;
+                }
+                const float e = 1.0f - rtd::exp_f(-0.0f * a.exposure);
+                w.out[i] = make_float4(e, e, e, __uint_as_float(0u));
+                w.outRays[i] = 0;
+            }
+        }
+    }
+    wf_queue(w, 0, (int)stripe)[off] = entry;
+}
+
+#ifndef RT_WF_OCC
+#define RT_WF_OCC 4
+#endif
+// closest-hit queries of one level: persistent waves, each lane refilled from the queue as soon as
+// the wave's share of finished lanes makes it worth leaving the traversal loops
+__global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderArgs a, const WfBufs w, const int level)
+{
+    __shared__ uint32_t ldsStack[kWfStack * kBlock];
+    __shared__ uint32_t poolSlot[kBlock];
+    __shared__ uint32_t wgCnt[8];
+    HotStackT<kWfStack> stack; stack.lds = ldsStack + threadIdx.x; stack.dropped = false;
+    const int lane = threadIdx.x & 63;
+    uint32_t* slotx = poolSlot + (threadIdx.x & ~63);
+    LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
+
+    const uint32_t waveId = blockIdx.x * 4u + (threadIdx.x >> 6);
+    uint32_t stripe = waveId % kWfStripes;
+    unsigned long long exhausted = 0ull, poolMask = 0ull;
+    uint32_t poolVal = kWfHole;
+    bool noMore = false, have = false;
+    uint32_t slot = 0;
+    Ray ray; ray.ox = ray.oy = ray.oz = ray.dx = ray.dy = ray.dz = 0.0f; ray.maxDist = 0.0f;
+    Trav T; trav_begin(T, a.scene, ray, stack); T.node = kTravEnd;
+
+    for (;;) {
+        // ---- results of the lanes that finished
+        if (have && !trav_running(T)) {
+            bool danger = false;
+            const Hit h = trav_result(T, ray, danger);
+            if (stack.dropped) { danger = true; stack.dropped = false; }
+            if (danger) st.slow++;
+            w.hitA[slot] = make_float4(h.t, h.b0, h.b1, h.b2);
+            w.hitG[slot] = (h.gid == kNoHit ? kWfMiss : h.gid) | (danger ? kWfDanger : 0u);
+            have = false;
+        }
+        // ---- refill from the queue
+        unsigned long long need = __ballot(!have && !noMore);
+        while (need != 0ull) {
+            if (poolMask == 0ull) {
+                int base = -1, n = 0;
+                if (lane == 0) {
+                    for (int k = 0; k < kWfStripes && base < 0; k++) {
+                        const uint32_t sidx = (stripe + (uint32_t)k) % kWfStripes;
+                        if (exhausted & (1ull << sidx)) continue;
+                        const uint32_t cnt = *wf_count(w, level, (int)sidx);
+                        const uint32_t c = cnt ? atomicAdd(wf_cursor(w, level, (int)sidx), 64u) : 0u;
+                        if (c < cnt) { base = (int)(sidx * w.subCap + c); n = (int)(cnt - c < 64u ? cnt - c : 64u); stripe = sidx; }
+                        else exhausted |= 1ull << sidx;
+                    }
+                }
+                base = __shfl(base, 0); n = __shfl(n, 0);
+                if (base < 0) { noMore = true; break; }
+                poolVal = lane < n ? (w.queue + (size_t)(level & 1) * kWfStripes * (size_t)w.subCap)[(uint32_t)base + (uint32_t)lane] : kWfHole;
+                poolMask = __ballot(poolVal != kWfHole);
+                if (poolMask == 0ull) continue;
+            }
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if ((poolMask >> lane) & 1ull) slotx[__popcll(poolMask & below)] = poolVal;
+            const int rank = __popcll(need & below);
+            const int avail = __popcll(poolMask);
+            const bool want = (need >> lane) & 1ull;
+            __builtin_amdgcn_wave_barrier();
+            if (want && rank < avail) {
+                slot = slotx[rank];
+                const float4 o = w.rayO[slot], d = w.rayD[slot];
+                ray.ox = o.x; ray.oy = o.y; ray.oz = o.z; ray.maxDist = o.w; ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
+                trav_begin(T, a.scene, ray, stack);
+                have = true;
+            }
+            __builtin_amdgcn_wave_barrier();
+            int k = __popcll(__ballot(want && rank < avail));
+            unsigned long long m = poolMask;
+            while (k-- > 0) m &= m - 1ull;
+            poolMask = m;
+            need = __ballot(!have && !noMore);
+        }
+        if (__ballot(have) == 0ull) break;
+        // ---- traversal burst
+        const bool running = have && trav_running(T);
+        const int nRun = __popcll(__ballot(running));
+        if (running) trav_burst(T, a.scene, ray, stack, st.bvh, noMore ? 1 : (nRun * kKeepNum + kKeepDen - 1) / kKeepDen);
+    }
+    flush_stats(a, st, wgCnt);
+}
+
+// material evaluation, BRDF and bounce ray of one level (:172-242): one lane per live path
+__global__ __launch_bounds__(256) void wf_shade_kernel(const RenderArgs a, const WfBufs w, const int level)
+{
+    __shared__ uint32_t wgCnt[8];
+    LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
+    const int lane = threadIdx.x & 63;
+    const uint32_t piecesPerStripe = (w.subCap + 255u) / 256u;
+    const uint32_t total = piecesPerStripe * kWfStripes;
+    for (uint32_t piece = blockIdx.x; piece < total; piece += gridDim.x) {
+        const uint32_t stripe = piece % kWfStripes, off = (piece / kWfStripes) * 256u + threadIdx.x;
+        const uint32_t cnt = *wf_count(w, level, (int)stripe);
+        if ((piece / kWfStripes) * 256u >= cnt) continue; // uniform per workgroup
+        const uint32_t slot = off < cnt ? wf_queue(w, level, (int)stripe)[off] : kWfHole;
+        bool more = false;
+        if (slot != kWfHole) {
+            const uint32_t spp = a.sampleCount;
+            const uint32_t pix = slot / spp, sidx = slot - pix * spp;
+            const float4 o = w.rayO[slot], d = w.rayD[slot], hA = w.hitA[slot], aO = w.accO[slot], aB = w.accB[slot];
+            const uint32_t hG = w.hitG[slot];
+            Ray ray; ray.ox = o.x; ray.oy = o.y; ray.oz = o.z; ray.maxDist = o.w; ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
+            uint32_t seed = __float_as_uint(d.w), checksum = __float_as_uint(aO.w);
+            PathAcc acc; acc.ox = aO.x; acc.oy = aO.y; acc.oz = aO.z; acc.bx = aB.x; acc.by = aB.y; acc.bz = aB.z;
+            Hit h; h.t = hA.x; h.b0 = hA.y; h.b1 = hA.z; h.b2 = hA.w;
+            h.gid = (hG & kWfMiss) == kWfMiss ? kNoHit : (hG & kWfMiss);
+            bool danger = (hG & kWfDanger) != 0u;
+            uint32_t cullObj = kNoHit;
+            const float m0 = ray.maxDist;
+            if (h.gid != kNoHit) { cullObj = a.scene.triRef[h.gid].obj; ray.maxDist = h.t; }
+            uint32_t primary[3] = { kNoHit, kNoHit, kNoHit };
+            more = shade_segment(a, h, ray, seed, sidx, level, acc, st, checksum, primary, cullObj, m0, &danger);
+            if (danger) w.pixFlag[pix] = 1u;
+            if (level == 0 && sidx == 0 && a.ids) {
+                int x, y;
+                wf_pixel(a, w, pix, x, y);
+                uint32_t* idp = reinterpret_cast<uint32_t*>(a.ids + ((size_t)y * (size_t)a.width + (size_t)x));
+                idp[0] = primary[0]; idp[1] = primary[1]; idp[2] = primary[2];
+            }
+            if (more) {
+                w.rayO[slot] = make_float4(ray.ox, ray.oy, ray.oz, ray.maxDist);
+                w.rayD[slot] = make_float4(ray.dx, ray.dy, ray.dz, __uint_as_float(seed));
+                w.accO[slot] = make_float4(acc.ox, acc.oy, acc.oz, __uint_as_float(checksum));
+                w.accB[slot] = make_float4(acc.bx, acc.by, acc.bz, 0.0f);
+            } else { // exposureCorrection (:690-698), per sample
+                w.out[slot] = make_float4(1.0f - rtd::exp_f(-acc.ox * a.exposure), 1.0f - rtd::exp_f(-acc.oy * a.exposure),
+                                          1.0f - rtd::exp_f(-acc.oz * a.exposure), __uint_as_float(checksum));
+                w.outRays[slot] = (uint8_t)(level + 1 > 255 ? 255 : level + 1);
+            }
+        }
+        // survivors go to the same stripe of the next level's queue: one atomic per wave
+        const unsigned long long mm = __ballot(more);
+        if (mm != 0ull) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(wf_count(w, level + 1, (int)stripe), (uint32_t)__popcll(mm));
+            base = __shfl(base, 0);
+            if (more) wf_queue(w, level + 1, (int)stripe)[base + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = slot;
+        }
+    }
+    flush_stats(a, st, wgCnt);
+}
+
+// :88-137: per pixel, the sample results in the reference's summation order
+__global__ __launch_bounds__(256) void wf_resolve_kernel(const RenderArgs a, const WfBufs w)
+{
+    __shared__ uint32_t wgCnt[8];
+    LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
+    const uint32_t pix = blockIdx.x * 256u + threadIdx.x;
+    int x, y;
+    if (pix < w.nPix && wf_pixel(a, w, pix, x, y)) {
+        if (w.pixFlag[pix] != 0u) {
+            const uint32_t k = atomicAdd(a.redoCount, 1u);
+            a.redoList[k] = (uint32_t)y * (uint32_t)a.width + (uint32_t)x;
+        } else {
+            const uint32_t spp = a.sampleCount;
+            const float4* o = w.out + (size_t)pix * spp;
+            const uint8_t* r = w.outRays + (size_t)pix * spp;
+            float tr = 0.0f, tg = 0.0f, tb = 0.0f;
+            uint32_t checksum = 0, rays = 0;
+            for (uint32_t z = 0; z < 4u; z++) {
+                float pr = 0.0f, pg = 0.0f, pb = 0.0f; // a z lane without samples contributes 0
+                for (uint32_t sidx = z; sidx < spp; sidx += 4u) {
+                    const float4 v = o[sidx];
+                    pr += v.x; pg += v.y; pb += v.z;
+                    checksum += __float_as_uint(v.w);
+                    rays += r[sidx];
+                }
+                tr += pr; tg += pg; tb += pb;
+            }
+            st.rays = rays;
+            write_pixel(a, x, y, tr, tg, tb, nullptr, checksum);
+        }
+    }
+    flush_stats(a, st, wgCnt);
+}
+
 // mode 0: persistent path kernel + redo launch for the pixels it flagged; mode 1: brute force
 void launch_render(const RenderArgs& a, int mode, int numCUs, hipStream_t stream)
 {
@@ -765,6 +1017,43 @@ void launch_render(const RenderArgs& a, int mode, int numCUs, hipStream_t stream
     if (grid < 8u) grid = 8u;
     hipLaunchKernelGGL(path_kernel, dim3(grid), dim3(256), 0, stream, b);
     // redo launch: exits at once when nothing was flagged
+    RenderArgs c = b;
+    c.pixelList = b.redoList; c.pixelCount = b.redoCount;
+    hipLaunchKernelGGL((render_kernel<2, 2>), dim3(256), dim3(256), 0, stream, c);
+}
+
+// mode 2: wavefront pipeline + redo launch.  `proto` holds the workspace (capacity capSlots slots);
+// the render rectangle is cut into chunks of whole 8x8 tiles that fit it.
+void launch_render_wf(const RenderArgs& a, const WfBufs& proto, uint32_t capSlots, int numCUs, hipStream_t stream)
+{
+    if (a.x1 <= a.x0 || a.y1 <= a.y0) return;
+    RenderArgs b = a;
+    b.tiles8X = (a.x1 - a.x0 + 7) / 8;
+    b.tiles8Y = (a.y1 - a.y0 + 7) / 8;
+    b.pixelList = nullptr; b.pixelCount = nullptr;
+    const uint32_t nTiles = (uint32_t)b.tiles8X * (uint32_t)b.tiles8Y;
+    const uint32_t spp = a.sampleCount;
+    uint32_t tilesPerChunk = capSlots / (64u * spp);
+    if (tilesPerChunk == 0) return; // rt_render sizes the workspace for at least one tile
+    const int levels = a.bounceCount > 0 ? a.bounceCount : 0;
+    for (uint32_t t0 = 0; t0 < nTiles; t0 += tilesPerChunk) {
+        WfBufs w = proto;
+        const uint32_t nt = nTiles - t0 < tilesPerChunk ? nTiles - t0 : tilesPerChunk;
+        w.tileBegin = t0; w.nPix = nt * 64u; w.nSlots = w.nPix * spp;
+        const uint32_t nPieces = (w.nSlots + 255u) / 256u;
+        hipMemsetAsync(w.ctrl, 0, sizeof(uint32_t) * (size_t)(levels + 1) * 2 * kWfStripes * kWfCtrlStride, stream);
+        hipLaunchKernelGGL(wf_gen_kernel, dim3(nPieces), dim3(256), 0, stream, b, w);
+        uint32_t gridT = (uint32_t)numCUs * RT_WF_OCC;
+        const uint32_t needT = (nPieces + 3u) / 4u; // never more waves than 64-entry grabs
+        if (gridT > needT) gridT = needT;
+        uint32_t gridS = (uint32_t)numCUs * 8u;
+        if (gridS > nPieces) gridS = nPieces;
+        for (int level = 0; level < levels; level++) {
+            hipLaunchKernelGGL(wf_trace_kernel, dim3(gridT), dim3(256), 0, stream, b, w, level);
+            hipLaunchKernelGGL(wf_shade_kernel, dim3(gridS), dim3(256), 0, stream, b, w, level);
+        }
+        hipLaunchKernelGGL(wf_resolve_kernel, dim3((w.nPix + 255u) / 256u), dim3(256), 0, stream, b, w);
+    }
     RenderArgs c = b;
     c.pixelList = b.redoList; c.pixelCount = b.redoCount;
     hipLaunchKernelGGL((render_kernel<2, 2>), dim3(256), dim3(256), 0, stream, c);

@@ -329,20 +329,21 @@ struct Stack {
 // LDS-only stack of the hot kernel: a push beyond kLdsStack entries is dropped and remembered; the
 // pixel is then re-rendered by the redo launch (which uses Stack), so the hot loops carry no
 // scratch path at all.
-struct HotStack {
+template <int CAP>
+struct HotStackT {
     uint32_t* lds;
     bool dropped;
     __device__ __forceinline__ void reset(int& sp) { lds[0] = (uint32_t)kTravEnd; sp = 1; }
     __device__ __forceinline__ void push(int& sp, uint32_t v)
     {
-        if (sp < kLdsStack) { lds[sp * kBlock] = v; sp++; }
+        if (sp < CAP) { lds[sp * kBlock] = v; sp++; }
         else dropped = true;
     }
     __device__ __forceinline__ uint32_t pop(int& sp) { --sp; return lds[sp * kBlock]; }
     // three independent predicated stores, no bounds test per entry
     __device__ __forceinline__ void push_far(int& sp, int h, uint32_t c1, uint32_t c2, uint32_t c3)
     {
-        if (sp + 3 > kLdsStack) { dropped = dropped || h >= 2; return; }
+        if (sp + 3 > CAP) { dropped = dropped || h >= 2; return; }
         uint32_t* top = lds + (sp + h) * kBlock;
         if (h >= 2) top[-2 * kBlock] = c1;
         if (h >= 3) top[-3 * kBlock] = c2;
@@ -350,6 +351,7 @@ struct HotStack {
         sp += h >= 2 ? h - 1 : 0;
     }
 };
+using HotStack = HotStackT<kLdsStack>;
 
 // Band inside which a hit on a different object triggers the exact in-order emulation.
 __device__ __forceinline__ float band_of(float t, float rayScale) { return 2e-4f * (t + rayScale); }
@@ -559,7 +561,8 @@ struct Trav {
     TriRay q;
     BoxRay br;
 };
-__device__ __forceinline__ void trav_begin(Trav& T, const SceneView& s, const Ray& ray, HotStack& stack)
+template <class HS>
+__device__ __forceinline__ void trav_begin(Trav& T, const SceneView& s, const Ray& ray, HS& stack)
 {
     T.q = make_tri_ray(ray);
     T.br = make_box_ray(ray, s.sceneMaxAbs);
@@ -576,7 +579,8 @@ __device__ __forceinline__ void trav_begin(Trav& T, const SceneView& s, const Ra
 __device__ __forceinline__ bool trav_running(const Trav& T) { return T.node != kTravEnd || T.triCount != 0u; }
 
 // a leaf in `node` becomes the pending triangle range once the previous range is used up
-__device__ __forceinline__ void trav_take_leaf(Trav& T, const SceneView& s, HotStack& stack)
+template <class HS>
+__device__ __forceinline__ void trav_take_leaf(Trav& T, const SceneView& s, HS& stack)
 {
     if (T.triCount == 0u && T.node < 0) {
         const uint32_t code = (uint32_t)(~T.node);
@@ -585,7 +589,8 @@ __device__ __forceinline__ void trav_take_leaf(Trav& T, const SceneView& s, HotS
     }
 }
 
-__device__ __forceinline__ void trav_tri_step(Trav& T, const SceneView& s, const Ray& ray, HotStack& stack, BvhCounters& cnt)
+template <class HS>
+__device__ __forceinline__ void trav_tri_step(Trav& T, const SceneView& s, const Ray& ray, HS& stack, BvhCounters& cnt)
 {
     if (T.triCount != 0u) {
         const float4* p = reinterpret_cast<const float4*>(s.triLeaf + T.triFirst);
@@ -618,7 +623,8 @@ __device__ __forceinline__ void trav_tri_step(Trav& T, const SceneView& s, const
 #define RT_TRI_DEN 4
 // Runs traversal steps for the calling lanes (all of them still traversing) until fewer than
 // `keep` of them remain; the others wait at the reconvergence point with their result.
-__device__ __forceinline__ void trav_burst(Trav& T, const SceneView& s, const Ray& ray, HotStack& stack,
+template <class HS>
+__device__ __forceinline__ void trav_burst(Trav& T, const SceneView& s, const Ray& ray, HS& stack,
                                            BvhCounters& cnt, int keep)
 {
 #ifdef RT_LOOP_TIMERS
@@ -662,16 +668,24 @@ __device__ __forceinline__ void trav_burst(Trav& T, const SceneView& s, const Ra
 }
 
 // Closest hit of a finished traversal; `danger` = another object has a hit inside the tie band.
-__device__ __forceinline__ Hit trav_finish(Trav& T, const SceneView& s, Ray& ray, bool& danger)
+__device__ __forceinline__ Hit trav_result(const Trav& T, Ray& ray, bool& danger)
 {
     if (T.best.gid != kNoHit) {
         const float limit = T.best.t + band_of(T.best.t, T.rayScale);
         if (T.otherT <= limit) danger = true;
-        cull_lookup(s, ray, T.bestObj, T.cc);
-        if (!object_cull_pass(T.cc.tmin, T.cc.bfar, T.m0)) danger = true;
         ray.maxDist = T.best.t;
     }
     return T.best;
+}
+
+// ... plus the object-space cull of the winner's object, which the triangle steps skip
+__device__ __forceinline__ Hit trav_finish(Trav& T, const SceneView& s, Ray& ray, bool& danger)
+{
+    if (T.best.gid != kNoHit) {
+        cull_lookup(s, ray, T.bestObj, T.cc);
+        if (!object_cull_pass(T.cc.tmin, T.cc.bfar, T.m0)) danger = true;
+    }
+    return trav_result(T, ray, danger);
 }
 
 // the reference loop itself with the BVH used for culling only: every object with an accepted hit,

@@ -39,7 +39,7 @@ def check(ref, rid, nq, img, ids, stats):
     assert psnr(img[..., :3], ref[..., :3]) >= 60.0
 
 
-@pytest.mark.parametrize("mode", [1, 0], ids=["brute", "bvh"])
+@pytest.mark.parametrize("mode", [1, 0, 2], ids=["brute", "bvh-wavefront", "bvh-persistent"])
 @pytest.mark.parametrize("spp,depth", [(1, 4), (2, 3), (3, 4), (4, 4), (6, 2), (9, 4)])
 def test_config1(ctx, mode, spp, depth):
     scene, cam, st = scenes.config1(256, 256, spp, depth)
@@ -57,7 +57,7 @@ from raytracer_amd.scene import Camera, Cube, Material, Mesh, MeshObject, Render
 GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_golden.npz"))
 
 
-def compare_modes(ctx, flat, cam, st, exact=True, modes=(1, 0)):
+def compare_modes(ctx, flat, cam, st, exact=True, modes=(1, 0, 2)):
     ref, rid, nq = orc.render(flat, cam, st)
     stats = None
     for mode in modes:
@@ -68,7 +68,7 @@ def compare_modes(ctx, flat, cam, st, exact=True, modes=(1, 0)):
     return ref, rid, stats
 
 
-@pytest.mark.parametrize("mode", [1, 0], ids=["brute", "bvh"])
+@pytest.mark.parametrize("mode", [1, 0, 2], ids=["brute", "bvh-wavefront", "bvh-persistent"])
 def test_committed_goldens(ctx, mode):
     for name, (spp, depth, aa) in {"c1_s1": (1, 4, True), "c1_s5": (5, 3, True), "c1_noaa": (1, 2, False)}.items():
         scene, cam, st = scenes.config1(64, 64, spp, depth)

@@ -7,6 +7,15 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpu
 python3 - <<PY
 import csv,glob
 f=glob.glob("$R/gpurun_out/ks_$tag/*/*_kernel_stats.csv")[0]
-for r in list(csv.DictReader(open(f)))[:4]:
-    print("$tag", r["Name"][:45], r["Calls"], "avg_ms %.3f" % (float(r["AverageNs"])/1e6))
+for r in list(csv.DictReader(open(f)))[:8]:
+    print("$tag", r["Name"][:50], r["Calls"], "avg_ms %.3f total_ms %.2f" % (float(r["AverageNs"])/1e6, float(r["TotalDurationNs"])/1e6))
+t=glob.glob("$R/gpurun_out/ks_$tag/*/*_kernel_trace.csv")[0]
+rows=[r for r in csv.DictReader(open(t)) if "wf_" in r["Kernel_Name"]]
+rows.sort(key=lambda r:int(r["Start_Timestamp"]))
+# last frame: the last len/7 launches
+n=len(rows)//7
+for r in rows[-n:]:
+    print("   %-40s %.3f ms" % (r["Kernel_Name"][:40], (int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6))
+if rows[-n:]:
+    print("   frame span %.3f ms" % ((int(rows[-1]["End_Timestamp"])-int(rows[-n]["Start_Timestamp"]))/1e6))
 PY

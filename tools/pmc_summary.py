@@ -10,7 +10,7 @@ for f in glob.glob(root + "/pass*/**/*counter_collection.csv", recursive=True):
         nd[k][r["Counter_Name"]].add(r["Dispatch_Id"])
 out = {}
 for k in acc:
-    if not ("path_kernel" in k or "render_kernel" in k):
+    if not ("path_kernel" in k or "render_kernel" in k or "wf_" in k):
         continue
     out[k] = {c: acc[k][c] / max(1, len(nd[k][c])) for c in sorted(acc[k])}
     out[k]["dispatches"] = max(len(v) for v in nd[k].values())
