@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--brute", action="store_true", help="reference-order brute force instead of the BVH")
     ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "persistent"],
                     help="BVH render pipeline: per-bounce trace/shade launches (default) or the single persistent kernel")
+    ap.add_argument("--wf-lanes", type=int, default=0, help="chunks in flight (HIP streams) of the wavefront pipeline (0 = library default)")
     ap.add_argument("--wf-chunk", type=int, default=0, help="samples in flight per chunk of the wavefront pipeline (0 = library default)")
     args = ap.parse_args()
 
@@ -94,6 +95,8 @@ def main():
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
     ctx.set_option(capi.OPT_TRAVERSAL, 1 if args.brute else (0 if args.pipeline == "wavefront" else 2))
+    if args.wf_lanes:
+        ctx.set_option(capi.OPT_WF_LANES, args.wf_lanes)
     if args.wf_chunk:
         ctx.set_option(capi.OPT_WF_CHUNK, args.wf_chunk)
     t0 = time.time()

@@ -92,8 +92,9 @@ enum rt_option {
                              2 = BVH, single persistent kernel.  All three give the same pixels. */
     RT_OPT_COUNTERS = 2,  /* reserved */
     RT_OPT_ACCUMULATE_STATS = 3, /* 1 = rt_render no longer zeroes the counters; setting it zeroes them once */
-    RT_OPT_WF_CHUNK = 4   /* samples in flight per chunk of the wavefront pipeline (0 = default, 64 Mi); the
-                             workspace holds ~113 bytes per sample */
+    RT_OPT_WF_CHUNK = 4,  /* samples in flight per chunk of the wavefront pipeline (0 = default, 64 Mi); the
+                             workspace holds ~113 bytes per sample and lane */
+    RT_OPT_WF_LANES = 5   /* chunks in flight at once, each on its own HIP stream (0 = default, 4; 1..4) */
 };
 
 /* ---- context ---- */

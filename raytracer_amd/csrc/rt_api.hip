@@ -12,6 +12,7 @@ namespace {
 
 constexpr size_t kWorkBytes = sizeof(uint32_t) * 512;
 constexpr size_t kWfChunkDefault = 64u << 20;
+constexpr size_t kWfLaneMin = 2u << 20;   // samples below which another lane is not worth its launches
 constexpr size_t kCntBytes = sizeof(unsigned long long) * rt::kCounterSlots * rt::kCounterStride;
 
 thread_local std::string g_createError;
@@ -60,8 +61,9 @@ struct rt_ctx {
     bool renderedOnce = false;
     float commitMs = 0.0f;
     int optTraversal = 0;
+    int optWfLanes = rt::kWfMaxLanes;
     size_t optWfChunk = kWfChunkDefault;     // samples in flight per chunk of the wavefront pipeline
-    rt::WfBufs wf{}; size_t wfCapSlots = 0; int wfLevels = 0;   // its workspace, grown on demand
+    rt::WfLanes wf; size_t wfCapSlots = 0; int wfLevels = 0; int wfLanes = 0; // its lanes and their workspace (wf.bufs[0] owns the allocations)
     int optCounters = 0;
     int optAccumulate = 0;
     int numCUs = 256;
@@ -122,36 +124,49 @@ int check_material_desc(rt_ctx* c, const rt_material_desc* d)
 
 void free_wf(rt_ctx* c)
 {
-    hipFree(c->wf.rayO); hipFree(c->wf.rayD); hipFree(c->wf.hitA); hipFree(c->wf.hitG); hipFree(c->wf.accO); hipFree(c->wf.accB);
-    hipFree(c->wf.out); hipFree(c->wf.outRays); hipFree(c->wf.pixFlag); hipFree(c->wf.queue); hipFree(c->wf.ctrl);
-    c->wf = rt::WfBufs{}; c->wfCapSlots = 0; c->wfLevels = 0;
+    rt::WfBufs& w = c->wf.bufs[0];
+    hipFree(w.rayO); hipFree(w.rayD); hipFree(w.hitA); hipFree(w.hitG); hipFree(w.accO); hipFree(w.accB);
+    hipFree(w.out); hipFree(w.outRays); hipFree(w.pixFlag); hipFree(w.queue); hipFree(w.ctrl);
+    for (int j = 0; j < rt::kWfMaxLanes; j++) c->wf.bufs[j] = rt::WfBufs{};
+    c->wfCapSlots = 0; c->wfLevels = 0; c->wfLanes = 0;
 }
 
-// workspace of the wavefront pipeline: ~113 bytes per sample in flight
-hipError_t ensure_wf(rt_ctx* c, size_t slots, int levels)
+// workspace of the wavefront pipeline: ~113 bytes per sample in flight, `slots` samples per lane
+hipError_t ensure_wf(rt_ctx* c, size_t slots, int levels, int lanes)
 {
-    if (slots <= c->wfCapSlots && levels <= c->wfLevels) return hipSuccess;
+    if (slots <= c->wfCapSlots && levels <= c->wfLevels && lanes <= c->wfLanes) return hipSuccess;
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return e;
     if (slots < c->wfCapSlots) slots = c->wfCapSlots;
     if (levels < c->wfLevels) levels = c->wfLevels;
+    if (lanes < c->wfLanes) lanes = c->wfLanes;
     free_wf(c);
-    rt::WfBufs& w = c->wf;
+    rt::WfBufs w{};
     const size_t pieces = (slots + 255) / 256;
     w.subCap = (uint32_t)(((pieces + rt::kWfStripes - 1) / rt::kWfStripes) * 256);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.rayO, 16 * slots);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.rayD, 16 * slots);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.hitA, 16 * slots);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.hitG, 4 * slots);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.accO, 16 * slots);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.accB, 16 * slots);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.out, 16 * slots);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.outRays, slots);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.pixFlag, 4 * slots);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.queue, sizeof(uint32_t) * 2 * rt::kWfStripes * (size_t)w.subCap);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.ctrl, sizeof(uint32_t) * (size_t)(levels + 1) * 2 * rt::kWfStripes * rt::kWfCtrlStride);
+    const size_t queueWords = 2 * (size_t)rt::kWfStripes * w.subCap;
+    const size_t ctrlWords = (size_t)(levels + 1) * 2 * rt::kWfStripes * rt::kWfCtrlStride + rt::kWfCtrlStride;
+    const size_t all = slots * (size_t)lanes;
+    if (e == hipSuccess) e = hipMalloc((void**)&w.rayO, 16 * all);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.rayD, 16 * all);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.hitA, 16 * all);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.hitG, 4 * all);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.accO, 16 * all);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.accB, 16 * all);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.out, 16 * all);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.outRays, all);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.pixFlag, 4 * all);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.queue, sizeof(uint32_t) * queueWords * (size_t)lanes);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.ctrl, sizeof(uint32_t) * ctrlWords * (size_t)lanes);
+    c->wf.bufs[0] = w;
     if (e != hipSuccess) { free_wf(c); return e; }
-    c->wfCapSlots = slots; c->wfLevels = levels;
+    for (int j = 1; j < lanes; j++) {
+        rt::WfBufs v = w;
+        v.rayO += slots * j; v.rayD += slots * j; v.hitA += slots * j; v.hitG += slots * j; v.accO += slots * j; v.accB += slots * j;
+        v.out += slots * j; v.outRays += slots * j; v.pixFlag += slots * j; v.queue += queueWords * j; v.ctrl += ctrlWords * j;
+        c->wf.bufs[j] = v;
+    }
+    c->wfCapSlots = slots; c->wfLevels = levels; c->wfLanes = lanes;
     return hipSuccess;
 }
 
@@ -224,6 +239,11 @@ int rt_ctx_create(int device, rt_ctx** out)
     if (e == hipSuccess) e = hipMalloc((void**)&c->dCounters, kCntBytes);
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->hCounters, kCntBytes);
     if (e == hipSuccess) e = hipMalloc((void**)&c->dWork, kWorkBytes);
+    for (int j = 1; j < rt::kWfMaxLanes && e == hipSuccess; j++) {
+        e = hipStreamCreateWithFlags(&c->wf.streams[j], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->wf.join[j], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->wf.fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&c->evBegin);
     if (e == hipSuccess) e = hipEventCreate(&c->evEnd);
     for (int i = 0; i < 16 && e == hipSuccess; i++) e = hipEventCreate(&c->slots[i]);
@@ -254,6 +274,11 @@ int rt_ctx_destroy(rt_ctx* c)
     if (c->evBegin) hipEventDestroy(c->evBegin);
     if (c->evEnd) hipEventDestroy(c->evEnd);
     for (int i = 0; i < 16; i++) if (c->slots[i]) hipEventDestroy(c->slots[i]);
+    for (int j = 1; j < rt::kWfMaxLanes; j++) {
+        if (c->wf.streams[j]) { hipStreamSynchronize(c->wf.streams[j]); hipStreamDestroy(c->wf.streams[j]); }
+        if (c->wf.join[j]) hipEventDestroy(c->wf.join[j]);
+    }
+    if (c->wf.fork) hipEventDestroy(c->wf.fork);
     if (c->ownStream) hipStreamDestroy(c->ownStream);
     delete c;
     return RT_OK;
@@ -274,6 +299,9 @@ int rt_set_option(rt_ctx* c, int option, int value)
         if (value < 0 || value > 2)
             return fail(c, RT_ERR_INVALID, "RT_OPT_TRAVERSAL takes 0 (BVH, wavefront pipeline), 1 (brute force) or 2 (BVH, single persistent kernel)");
         c->optTraversal = value; return RT_OK;
+    case RT_OPT_WF_LANES:
+        if (value < 0 || value > rt::kWfMaxLanes) return fail(c, RT_ERR_INVALID, "RT_OPT_WF_LANES takes 0 (default) .. 4");
+        c->optWfLanes = value ? value : rt::kWfMaxLanes; return RT_OK;
     case RT_OPT_WF_CHUNK:
         if (value < 0) return fail(c, RT_ERR_INVALID, "RT_OPT_WF_CHUNK takes a sample count >= 0 (0 = default)");
         c->optWfChunk = value ? (size_t)value : kWfChunkDefault; return RT_OK;
@@ -684,15 +712,19 @@ int rt_render(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* 
     if (c->optTraversal == 0 && rnd->bounceCount <= 200) {
         const size_t tiles = (size_t)((tile.x1 - tile.x0 + 7) / 8) * (size_t)((tile.y1 - tile.y0 + 7) / 8);
         const size_t perTile = 64 * (size_t)rnd->sampleCount;
-        size_t chunkTiles = c->optWfChunk / perTile;
-        if (chunkTiles == 0) chunkTiles = 1;
-        if (chunkTiles > tiles) chunkTiles = tiles;
-        if (chunkTiles * perTile >= (1ull << 31)) return fail(c, RT_ERR_INVALID, "sampleCount too large for one 8x8 tile of the wavefront workspace");
+        if (perTile >= (1ull << 31)) return fail(c, RT_ERR_INVALID, "sampleCount too large for one 8x8 tile of the wavefront workspace");
         if (tiles > 0) {
-            hipError_t e = ensure_wf(c, chunkTiles * perTile, rnd->bounceCount > 0 ? rnd->bounceCount : 0);
+            // lanes: one per kWfLaneMin samples up to optWfLanes; chunks: whole tiles, at most optWfChunk samples each
+            int lanes = (int)((tiles * perTile) / kWfLaneMin);
+            lanes = lanes < 1 ? 1 : (lanes > c->optWfLanes ? c->optWfLanes : lanes);
+            size_t chunkTiles = (tiles + (size_t)lanes - 1) / (size_t)lanes;
+            const size_t capTiles = c->optWfChunk / perTile ? c->optWfChunk / perTile : 1;
+            if (chunkTiles > capTiles) chunkTiles = capTiles;
+            hipError_t e = ensure_wf(c, chunkTiles * perTile, rnd->bounceCount > 0 ? rnd->bounceCount : 0, lanes);
             if (e != hipSuccess) return fail(c, RT_ERR_HIP, std::string("wavefront workspace: ") + hipGetErrorString(e));
+            c->wf.n = lanes; c->wf.tilesPerChunk = (uint32_t)chunkTiles;
             RT_CHECK(c, hipEventRecord(c->evBegin, c->stream));
-            rt::launch_render_wf(a, c->wf, (uint32_t)c->wfCapSlots, c->numCUs, c->stream);
+            rt::launch_render_wf(a, c->wf, c->numCUs, c->stream);
         }
     } else {
         rt::launch_render(a, c->optTraversal == 1 ? 1 : 0, c->numCUs, c->stream);

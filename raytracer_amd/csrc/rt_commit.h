@@ -37,7 +37,17 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
 void free_scene(BuiltScene& s);
 
 void launch_render(const RenderArgs& a, int mode, int numCUs, hipStream_t stream);
-void launch_render_wf(const RenderArgs& a, const WfBufs& proto, uint32_t capSlots, int numCUs, hipStream_t stream);
+// lanes of the wavefront pipeline: lane 0 runs on the caller's stream, the others on streams[1..n-1]
+constexpr int kWfMaxLanes = 4;
+struct WfLanes {
+    int n = 0;
+    uint32_t tilesPerChunk = 0;
+    hipStream_t streams[kWfMaxLanes] = {};
+    hipEvent_t fork = nullptr;
+    hipEvent_t join[kWfMaxLanes] = {};
+    WfBufs bufs[kWfMaxLanes] = {};
+};
+void launch_render_wf(const RenderArgs& a, const WfLanes& L, int numCUs, hipStream_t mainStream);
 void launch_trace_rays(const SceneView& s, const float4* rays, int n, uint4* out, unsigned long long* counters, int mode,
                        hipStream_t stream);
 void launch_detmath(int op, const float* in, int n, float* out, hipStream_t stream);

@@ -14,6 +14,7 @@
 //  * gfx950 has no texture unit: bilinear filtering is done in software on RGBA8 texels
 //    (value = byte/255.0f at fetch, the reference's own conversion, Material.cu:203).
 #include "rt_trace.h"
+#include "rt_commit.h"
 
 namespace rt {
 
@@ -1022,9 +1023,12 @@ void launch_render(const RenderArgs& a, int mode, int numCUs, hipStream_t stream
     hipLaunchKernelGGL((render_kernel<2, 2>), dim3(256), dim3(256), 0, stream, c);
 }
 
-// mode 2: wavefront pipeline + redo launch.  `proto` holds the workspace (capacity capSlots slots);
-// the render rectangle is cut into chunks of whole 8x8 tiles that fit it.
-void launch_render_wf(const RenderArgs& a, const WfBufs& proto, uint32_t capSlots, int numCUs, hipStream_t stream)
+// Wavefront pipeline + redo launches.  The render rectangle is cut into chunks of whole 8x8 tiles;
+// chunk k runs on lane k % n (a lane = a HIP stream with its own workspace).  The lanes exist for
+// the tails: a level's trace launch ends with its slowest ray, traversed by one lane of one wave
+// at memory latency (measured on the 1 M-triangle scene: waves alive 53 % of the launch, the SQs
+// busy 57 %), and with several lanes in flight the other chunks' launches fill the machine meanwhile.
+void launch_render_wf(const RenderArgs& a, const WfLanes& L, int numCUs, hipStream_t mainStream)
 {
     if (a.x1 <= a.x0 || a.y1 <= a.y0) return;
     RenderArgs b = a;
@@ -1033,30 +1037,50 @@ void launch_render_wf(const RenderArgs& a, const WfBufs& proto, uint32_t capSlot
     b.pixelList = nullptr; b.pixelCount = nullptr;
     const uint32_t nTiles = (uint32_t)b.tiles8X * (uint32_t)b.tiles8Y;
     const uint32_t spp = a.sampleCount;
-    uint32_t tilesPerChunk = capSlots / (64u * spp);
-    if (tilesPerChunk == 0) return; // rt_render sizes the workspace for at least one tile
+    const uint32_t tilesPerChunk = L.tilesPerChunk;
+    if (tilesPerChunk == 0 || L.n <= 0) return;
     const int levels = a.bounceCount > 0 ? a.bounceCount : 0;
-    for (uint32_t t0 = 0; t0 < nTiles; t0 += tilesPerChunk) {
-        WfBufs w = proto;
+    const size_t ctrlWords = (size_t)(levels + 1) * 2 * kWfStripes * kWfCtrlStride + kWfCtrlStride;
+    const uint32_t nChunks = (nTiles + tilesPerChunk - 1) / tilesPerChunk;
+    const int used = (int)(nChunks < (uint32_t)L.n ? nChunks : (uint32_t)L.n);
+    if (used > 1) {
+        hipEventRecord(L.fork, mainStream);
+        for (int j = 1; j < used; j++) hipStreamWaitEvent(L.streams[j], L.fork, 0);
+    }
+    for (uint32_t k = 0; k < nChunks; k++) {
+        const int j = (int)(k % (uint32_t)used);
+        hipStream_t stream = j == 0 ? mainStream : L.streams[j];
+        WfBufs w = L.bufs[j];
+        const uint32_t t0 = k * tilesPerChunk;
         const uint32_t nt = nTiles - t0 < tilesPerChunk ? nTiles - t0 : tilesPerChunk;
         w.tileBegin = t0; w.nPix = nt * 64u; w.nSlots = w.nPix * spp;
         const uint32_t nPieces = (w.nSlots + 255u) / 256u;
-        hipMemsetAsync(w.ctrl, 0, sizeof(uint32_t) * (size_t)(levels + 1) * 2 * kWfStripes * kWfCtrlStride, stream);
-        hipLaunchKernelGGL(wf_gen_kernel, dim3(nPieces), dim3(256), 0, stream, b, w);
+        RenderArgs c = b;
+        c.redoCount = w.ctrl + (ctrlWords - kWfCtrlStride);
+        c.redoList = b.redoList + (size_t)t0 * 64u;
+        hipMemsetAsync(w.ctrl, 0, sizeof(uint32_t) * ctrlWords, stream);
+        hipLaunchKernelGGL(wf_gen_kernel, dim3(nPieces), dim3(256), 0, stream, c, w);
         uint32_t gridT = (uint32_t)numCUs * RT_WF_OCC;
         const uint32_t needT = (nPieces + 3u) / 4u; // never more waves than 64-entry grabs
         if (gridT > needT) gridT = needT;
         uint32_t gridS = (uint32_t)numCUs * 8u;
         if (gridS > nPieces) gridS = nPieces;
         for (int level = 0; level < levels; level++) {
-            hipLaunchKernelGGL(wf_trace_kernel, dim3(gridT), dim3(256), 0, stream, b, w, level);
-            hipLaunchKernelGGL(wf_shade_kernel, dim3(gridS), dim3(256), 0, stream, b, w, level);
+            hipLaunchKernelGGL(wf_trace_kernel, dim3(gridT), dim3(256), 0, stream, c, w, level);
+            hipLaunchKernelGGL(wf_shade_kernel, dim3(gridS), dim3(256), 0, stream, c, w, level);
         }
-        hipLaunchKernelGGL(wf_resolve_kernel, dim3((w.nPix + 255u) / 256u), dim3(256), 0, stream, b, w);
+        hipLaunchKernelGGL(wf_resolve_kernel, dim3((w.nPix + 255u) / 256u), dim3(256), 0, stream, c, w);
+        // redo launch for the pixels this chunk flagged: exits at once when there is none
+        RenderArgs r = c;
+        r.pixelList = c.redoList; r.pixelCount = c.redoCount;
+        uint32_t gridR = (w.nPix + 63u) / 64u;
+        if (gridR > 256u) gridR = 256u;
+        hipLaunchKernelGGL((render_kernel<2, 2>), dim3(gridR), dim3(256), 0, stream, r);
     }
-    RenderArgs c = b;
-    c.pixelList = b.redoList; c.pixelCount = b.redoCount;
-    hipLaunchKernelGGL((render_kernel<2, 2>), dim3(256), dim3(256), 0, stream, c);
+    for (int j = 1; j < used; j++) {
+        hipEventRecord(L.join[j], L.streams[j]);
+        hipStreamWaitEvent(mainStream, L.join[j], 0);
+    }
 }
 
 void launch_trace_rays(const SceneView& s, const float4* rays, int n, uint4* out, unsigned long long* counters, int mode,
