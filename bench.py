@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--spp", type=int, default=0)
     ap.add_argument("--depth", type=int, default=0)
-    ap.add_argument("--cpu-crop", type=int, default=192, help="side of the centred crop the CPU baseline renders")
+    ap.add_argument("--cpu-crop", type=int, default=448, help="side of the centred crop the CPU baseline renders")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--brute", action="store_true", help="reference-order brute force instead of the BVH")
     ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "persistent"],
@@ -170,8 +170,12 @@ def main():
         samples_local = W * H * st.sampleCount * args.steps if args.mode == "frames" else sum(
             (r[2] - r[0]) * (r[3] - r[1]) for r in rects) * st.sampleCount * args.steps
         pix_local = samples_local / st.sampleCount
+        # wavefront pipeline: per closest-hit query the path state crosses HBM between the launches
+        # (trace: ray 32 + queue 4 in, hit 20 out; shade: ray 32 + hit 20 + state 32 + queue 4 in,
+        # ray 32 + state 32 + queue 4 out) and per sample 16 + 1 bytes of result out and in again
+        state_b = (32 + 4 + 20) + (32 + 20 + 32 + 4) + (32 + 32 + 4) if args.pipeline == "wavefront" and not args.brute else 0.0
         alg_bytes = (s.node_visits * node_b + s.tri_tests * tri_b + s.hits * (shade_b + tex_per_hit)
-                     + samples_local * 64.0 + pix_local * 16.0)
+                     + rays_local * state_b + samples_local * (64.0 + (34.0 if state_b else 0.0)) + pix_local * 16.0)
         alg_flops = s.node_visits * 44.0 + s.tri_tests * 45.0 + s.hits * 300.0 + samples_local * 60.0
         achieved_gbs = alg_bytes / launches / (kernel_ms * 1e-3) / 1e9
         achieved_tf = alg_flops / launches / (kernel_ms * 1e-3) / 1e12
@@ -204,7 +208,10 @@ def main():
                        "bvh_build_ms": float(s.commit_ms)},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "render_kernel", "kernel_ms": kernel_ms,
+                         "kernel": ("all launches of one rt_render call (wf_gen, wf_trace + wf_shade per bounce level, wf_resolve, redo); "
+                                    "wf_trace dominates, see profiles/") if args.pipeline == "wavefront" and not args.brute
+                         else ("path_kernel + redo" if not args.brute else "render_kernel (brute force)"),
+                         "kernel_ms": kernel_ms,
                          "bytes_per_ray": alg_bytes / max(1, rays_local), "nodes_per_ray": s.node_visits / max(1, rays_local),
                          "tris_per_ray": s.tri_tests / max(1, rays_local), "slow_path_frac": s.slow_path / max(1, rays_local),
                          "valu": {"achieved": achieved_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
