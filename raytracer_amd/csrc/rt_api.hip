@@ -694,7 +694,8 @@ int rt_render(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* 
     memcpy(a.skyDir, sky->direction, 16); memcpy(a.lightColor, sky->lightColor, 16); memcpy(a.skyColor, sky->skyColor, 16);
     a.x0 = tile.x0; a.y0 = tile.y0; a.x1 = tile.x1; a.y1 = tile.y1;
     a.fb = f.data; a.ids = f.idsEnabled ? f.ids : nullptr; a.counters = c->dCounters;
-    const size_t tilePixels = (size_t)(tile.x1 - tile.x0) * (size_t)(tile.y1 - tile.y0);
+    // padded to whole 8x8 tiles: the wavefront pipeline gives every chunk the slice [firstTile * 64, ...)
+    const size_t tilePixels = (size_t)((tile.x1 - tile.x0 + 7) / 8) * (size_t)((tile.y1 - tile.y0 + 7) / 8) * 64;
     if (tilePixels > c->redoCap) { // grows only when a larger tile than ever before is rendered
         RT_CHECK(c, hipStreamSynchronize(c->stream));
         hipFree(c->dRedoList); c->dRedoList = nullptr; c->redoCap = 0;

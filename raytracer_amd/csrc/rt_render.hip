@@ -955,37 +955,83 @@ __global__ __launch_bounds__(256) void wf_shade_kernel(const RenderArgs a, const
     flush_stats(a, st, wgCnt);
 }
 
-// :88-137: per pixel, the sample results in the reference's summation order
+// :88-137: per pixel, the sample results in the reference's summation order.
+// PASS 0: every pixel of the chunk; flagged ones are listed for wf_redo instead of written.
+// PASS 1: the listed pixels, after wf_redo has replaced their samples.
+__device__ __forceinline__ void wf_resolve_pixel(const RenderArgs& a, const WfBufs& w, uint32_t pix, int x, int y, LaneStats& st)
+{
+    const uint32_t spp = a.sampleCount;
+    const float4* o = w.out + (size_t)pix * spp;
+    const uint8_t* r = w.outRays + (size_t)pix * spp;
+    float tr = 0.0f, tg = 0.0f, tb = 0.0f;
+    uint32_t checksum = 0, rays = 0;
+    for (uint32_t z = 0; z < 4u; z++) {
+        float pr = 0.0f, pg = 0.0f, pb = 0.0f; // a z lane without samples contributes 0
+        for (uint32_t sidx = z; sidx < spp; sidx += 4u) {
+            const float4 v = o[sidx];
+            pr += v.x; pg += v.y; pb += v.z;
+            checksum += __float_as_uint(v.w);
+            rays += r[sidx];
+        }
+        tr += pr; tg += pg; tb += pb;
+    }
+    st.rays += rays;
+    write_pixel(a, x, y, tr, tg, tb, nullptr, checksum);
+}
+
+template <int PASS>
 __global__ __launch_bounds__(256) void wf_resolve_kernel(const RenderArgs a, const WfBufs w)
 {
     __shared__ uint32_t wgCnt[8];
     LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
-    const uint32_t pix = blockIdx.x * 256u + threadIdx.x;
     int x, y;
-    if (pix < w.nPix && wf_pixel(a, w, pix, x, y)) {
-        if (w.pixFlag[pix] != 0u) {
-            const uint32_t k = atomicAdd(a.redoCount, 1u);
-            a.redoList[k] = (uint32_t)y * (uint32_t)a.width + (uint32_t)x;
-        } else {
-            const uint32_t spp = a.sampleCount;
-            const float4* o = w.out + (size_t)pix * spp;
-            const uint8_t* r = w.outRays + (size_t)pix * spp;
-            float tr = 0.0f, tg = 0.0f, tb = 0.0f;
-            uint32_t checksum = 0, rays = 0;
-            for (uint32_t z = 0; z < 4u; z++) {
-                float pr = 0.0f, pg = 0.0f, pb = 0.0f; // a z lane without samples contributes 0
-                for (uint32_t sidx = z; sidx < spp; sidx += 4u) {
-                    const float4 v = o[sidx];
-                    pr += v.x; pg += v.y; pb += v.z;
-                    checksum += __float_as_uint(v.w);
-                    rays += r[sidx];
-                }
-                tr += pr; tg += pg; tb += pb;
-            }
-            st.rays = rays;
-            write_pixel(a, x, y, tr, tg, tb, nullptr, checksum);
+    if (PASS == 0) {
+        const uint32_t pix = blockIdx.x * 256u + threadIdx.x;
+        if (pix < w.nPix && wf_pixel(a, w, pix, x, y)) {
+            if (w.pixFlag[pix] != 0u) a.redoList[atomicAdd(a.redoCount, 1u)] = pix;
+            else wf_resolve_pixel(a, w, pix, x, y, st);
+        }
+    } else {
+        const uint32_t n = *a.redoCount;
+        for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) {
+            const uint32_t pix = a.redoList[k];
+            wf_pixel(a, w, pix, x, y);
+            wf_resolve_pixel(a, w, pix, x, y, st);
         }
     }
+    flush_stats(a, st, wgCnt);
+}
+
+// The flagged pixels again, one lane per sample, with the exact in-order emulation inline
+// (closest_hit<2>): tie bands between objects, culled winners, stack overflows.
+__global__ __launch_bounds__(256) void wf_redo_kernel(const RenderArgs a, const WfBufs w)
+{
+    __shared__ uint32_t ldsStack[kLdsStack * kBlock];
+    __shared__ uint32_t wgCnt[8];
+    uint32_t ovf[kStackDepth - kLdsStack];
+    Stack stack; stack.lds = ldsStack + threadIdx.x; stack.ovf = ovf;
+    LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
+    const uint32_t spp = a.sampleCount;
+    const unsigned long long n = (unsigned long long)(*a.redoCount) * spp;
+    for (unsigned long long item = blockIdx.x * 256u + threadIdx.x; item < n; item += (unsigned long long)gridDim.x * 256u) {
+        const uint32_t pix = a.redoList[item / spp], sidx = (uint32_t)(item % spp);
+        int x, y;
+        wf_pixel(a, w, pix, x, y);
+        uint32_t seed = sample_seed(a, x, y, sidx), checksum = 0;
+        uint32_t primary[3] = { kNoHit, kNoHit, kNoHit };
+        Ray ray = setup_ray(a, x, y, seed);
+        const uint32_t rays0 = st.rays;
+        const V4 c = trace_path<2>(a, ray, seed, sidx, stack, st, checksum, primary);
+        const size_t slot = (size_t)pix * spp + sidx;
+        w.out[slot] = make_float4(1.0f - rtd::exp_f(-c.x * a.exposure), 1.0f - rtd::exp_f(-c.y * a.exposure),
+                                  1.0f - rtd::exp_f(-c.z * a.exposure), __uint_as_float(checksum));
+        w.outRays[slot] = (uint8_t)(st.rays - rays0);
+        if (sidx == 0 && a.ids) {
+            uint32_t* idp = reinterpret_cast<uint32_t*>(a.ids + ((size_t)y * (size_t)a.width + (size_t)x));
+            idp[0] = primary[0]; idp[1] = primary[1]; idp[2] = primary[2];
+        }
+    }
+    st.rays = 0; // counted by the second resolve pass from outRays
     flush_stats(a, st, wgCnt);
 }
 
@@ -1069,13 +1115,12 @@ void launch_render_wf(const RenderArgs& a, const WfLanes& L, int numCUs, hipStre
             hipLaunchKernelGGL(wf_trace_kernel, dim3(gridT), dim3(256), 0, stream, c, w, level);
             hipLaunchKernelGGL(wf_shade_kernel, dim3(gridS), dim3(256), 0, stream, c, w, level);
         }
-        hipLaunchKernelGGL(wf_resolve_kernel, dim3((w.nPix + 255u) / 256u), dim3(256), 0, stream, c, w);
-        // redo launch for the pixels this chunk flagged: exits at once when there is none
-        RenderArgs r = c;
-        r.pixelList = c.redoList; r.pixelCount = c.redoCount;
-        uint32_t gridR = (w.nPix + 63u) / 64u;
-        if (gridR > 256u) gridR = 256u;
-        hipLaunchKernelGGL((render_kernel<2, 2>), dim3(gridR), dim3(256), 0, stream, r);
+        hipLaunchKernelGGL((wf_resolve_kernel<0>), dim3((w.nPix + 255u) / 256u), dim3(256), 0, stream, c, w);
+        // the pixels this chunk flagged, one lane per sample; both launches exit at once when there is none
+        uint32_t gridR = (w.nSlots + 255u) / 256u;
+        if (gridR > (uint32_t)numCUs * 4u) gridR = (uint32_t)numCUs * 4u;
+        hipLaunchKernelGGL(wf_redo_kernel, dim3(gridR), dim3(256), 0, stream, c, w);
+        hipLaunchKernelGGL((wf_resolve_kernel<1>), dim3(gridR > 64u ? 64u : gridR), dim3(256), 0, stream, c, w);
     }
     for (int j = 1; j < used; j++) {
         hipEventRecord(L.join[j], L.streams[j]);
