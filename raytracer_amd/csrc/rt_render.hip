@@ -761,6 +761,12 @@ __device__ __forceinline__ uint32_t* wf_queue(const WfBufs& w, int level, int st
 {
     return w.queue + ((size_t)(level & 1) * kWfStripes + stripe) * (size_t)w.subCap;
 }
+// finished-sample results are stored sample-major inside each 64-pixel tile, so that wf_resolve's
+// lanes (one pixel each) read consecutive addresses
+__device__ __forceinline__ size_t wf_out_index(uint32_t pix, uint32_t sidx, uint32_t spp)
+{
+    return ((size_t)(pix >> 6) * spp + sidx) * 64u + (pix & 63u);
+}
 // slot -> pixel; false when the pixel lies outside the render rectangle (edge tiles)
 __device__ __forceinline__ bool wf_pixel(const RenderArgs& a, const WfBufs& w, uint32_t pix, int& x, int& y)
 {
@@ -793,17 +799,15 @@ __global__ __launch_bounds__(256) void wf_gen_kernel(const RenderArgs a, const W
             if (a.bounceCount > 0) {
                 w.rayO[i] = make_float4(ray.ox, ray.oy, ray.oz, ray.maxDist);
                 w.rayD[i] = make_float4(ray.dx, ray.dy, ray.dz, __uint_as_float(seed));
-                w.accO[i] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
-                w.accB[i] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-                entry = i;
+                entry = i; // outgoing light 0, beta 1, checksum 0: wf_shade(0) supplies them
             } else { // the bounce loop does not run: radiance 0 (:172)
                 if (sidx == 0 && a.ids) {
                     uint32_t* idp = reinterpret_cast<uint32_t*>(a.ids + ((size_t)y * (size_t)a.width + (size_t)x));
                     idp[0] = kNoHit; idp[1] = kNoHit; idp[2] = kNoHit;
                 }
                 const float e = 1.0f - rtd::exp_f(-0.0f * a.exposure);
-                w.out[i] = make_float4(e, e, e, __uint_as_float(0u));
-                w.outRays[i] = 0;
+                w.out[wf_out_index(pix, sidx, spp)] = make_float4(e, e, e, __uint_as_float(0u));
+                w.outRays[wf_out_index(pix, sidx, spp)] = 0;
             }
         }
     }
@@ -912,7 +916,9 @@ __global__ __launch_bounds__(256) void wf_shade_kernel(const RenderArgs a, const
         if (slot != kWfHole) {
             const uint32_t spp = a.sampleCount;
             const uint32_t pix = slot / spp, sidx = slot - pix * spp;
-            const float4 o = w.rayO[slot], d = w.rayD[slot], hA = w.hitA[slot], aO = w.accO[slot], aB = w.accB[slot];
+            const float4 o = w.rayO[slot], d = w.rayD[slot], hA = w.hitA[slot];
+            const float4 aO = level == 0 ? make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u)) : w.accO[slot];
+            const float4 aB = level == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : w.accB[slot];
             const uint32_t hG = w.hitG[slot];
             Ray ray; ray.ox = o.x; ray.oy = o.y; ray.oz = o.z; ray.maxDist = o.w; ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
             uint32_t seed = __float_as_uint(d.w), checksum = __float_as_uint(aO.w);
@@ -938,9 +944,10 @@ __global__ __launch_bounds__(256) void wf_shade_kernel(const RenderArgs a, const
                 w.accO[slot] = make_float4(acc.ox, acc.oy, acc.oz, __uint_as_float(checksum));
                 w.accB[slot] = make_float4(acc.bx, acc.by, acc.bz, 0.0f);
             } else { // exposureCorrection (:690-698), per sample
-                w.out[slot] = make_float4(1.0f - rtd::exp_f(-acc.ox * a.exposure), 1.0f - rtd::exp_f(-acc.oy * a.exposure),
-                                          1.0f - rtd::exp_f(-acc.oz * a.exposure), __uint_as_float(checksum));
-                w.outRays[slot] = (uint8_t)(level + 1 > 255 ? 255 : level + 1);
+                const size_t oi = wf_out_index(pix, sidx, spp);
+                w.out[oi] = make_float4(1.0f - rtd::exp_f(-acc.ox * a.exposure), 1.0f - rtd::exp_f(-acc.oy * a.exposure),
+                                        1.0f - rtd::exp_f(-acc.oz * a.exposure), __uint_as_float(checksum));
+                w.outRays[oi] = (uint8_t)(level + 1 > 255 ? 255 : level + 1);
             }
         }
         // survivors go to the same stripe of the next level's queue: one atomic per wave
@@ -961,17 +968,16 @@ __global__ __launch_bounds__(256) void wf_shade_kernel(const RenderArgs a, const
 __device__ __forceinline__ void wf_resolve_pixel(const RenderArgs& a, const WfBufs& w, uint32_t pix, int x, int y, LaneStats& st)
 {
     const uint32_t spp = a.sampleCount;
-    const float4* o = w.out + (size_t)pix * spp;
-    const uint8_t* r = w.outRays + (size_t)pix * spp;
     float tr = 0.0f, tg = 0.0f, tb = 0.0f;
     uint32_t checksum = 0, rays = 0;
     for (uint32_t z = 0; z < 4u; z++) {
         float pr = 0.0f, pg = 0.0f, pb = 0.0f; // a z lane without samples contributes 0
         for (uint32_t sidx = z; sidx < spp; sidx += 4u) {
-            const float4 v = o[sidx];
+            const size_t oi = wf_out_index(pix, sidx, spp);
+            const float4 v = w.out[oi];
             pr += v.x; pg += v.y; pb += v.z;
             checksum += __float_as_uint(v.w);
-            rays += r[sidx];
+            rays += w.outRays[oi];
         }
         tr += pr; tg += pg; tb += pb;
     }
@@ -1022,10 +1028,10 @@ __global__ __launch_bounds__(256) void wf_redo_kernel(const RenderArgs a, const 
         Ray ray = setup_ray(a, x, y, seed);
         const uint32_t rays0 = st.rays;
         const V4 c = trace_path<2>(a, ray, seed, sidx, stack, st, checksum, primary);
-        const size_t slot = (size_t)pix * spp + sidx;
-        w.out[slot] = make_float4(1.0f - rtd::exp_f(-c.x * a.exposure), 1.0f - rtd::exp_f(-c.y * a.exposure),
-                                  1.0f - rtd::exp_f(-c.z * a.exposure), __uint_as_float(checksum));
-        w.outRays[slot] = (uint8_t)(st.rays - rays0);
+        const size_t oi = wf_out_index(pix, sidx, spp);
+        w.out[oi] = make_float4(1.0f - rtd::exp_f(-c.x * a.exposure), 1.0f - rtd::exp_f(-c.y * a.exposure),
+                                1.0f - rtd::exp_f(-c.z * a.exposure), __uint_as_float(checksum));
+        w.outRays[oi] = (uint8_t)(st.rays - rays0);
         if (sidx == 0 && a.ids) {
             uint32_t* idp = reinterpret_cast<uint32_t*>(a.ids + ((size_t)y * (size_t)a.width + (size_t)x));
             idp[0] = primary[0]; idp[1] = primary[1]; idp[2] = primary[2];
