@@ -131,7 +131,7 @@ void free_wf(rt_ctx* c)
     c->wfCapSlots = 0; c->wfLevels = 0; c->wfLanes = 0;
 }
 
-// workspace of the wavefront pipeline: ~113 bytes per sample in flight, `slots` samples per lane
+// workspace of the wavefront pipeline: ~180 bytes per sample in flight, `slots` samples per lane
 hipError_t ensure_wf(rt_ctx* c, size_t slots, int levels, int lanes)
 {
     if (slots <= c->wfCapSlots && levels <= c->wfLevels && lanes <= c->wfLanes) return hipSuccess;
@@ -147,12 +147,13 @@ hipError_t ensure_wf(rt_ctx* c, size_t slots, int levels, int lanes)
     const size_t queueWords = 2 * (size_t)rt::kWfStripes * w.subCap;
     const size_t ctrlWords = (size_t)(levels + 1) * 2 * rt::kWfStripes * rt::kWfCtrlStride + rt::kWfCtrlStride;
     const size_t all = slots * (size_t)lanes;
-    if (e == hipSuccess) e = hipMalloc((void**)&w.rayO, 16 * all);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.rayD, 16 * all);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.hitA, 16 * all);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.hitG, 4 * all);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.accO, 16 * all);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.accB, 16 * all);
+    const size_t allQ = queueWords * (size_t)lanes; // positions of both ping-pong halves, all lanes
+    if (e == hipSuccess) e = hipMalloc((void**)&w.rayO, 16 * allQ);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.rayD, 16 * allQ);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.accO, 16 * allQ);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.accB, 16 * allQ);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.hitA, 16 * (allQ / 2));
+    if (e == hipSuccess) e = hipMalloc((void**)&w.hitG, 4 * (allQ / 2));
     if (e == hipSuccess) e = hipMalloc((void**)&w.out, 16 * all);
     if (e == hipSuccess) e = hipMalloc((void**)&w.outRays, all);
     if (e == hipSuccess) e = hipMalloc((void**)&w.pixFlag, 4 * all);
@@ -162,7 +163,8 @@ hipError_t ensure_wf(rt_ctx* c, size_t slots, int levels, int lanes)
     if (e != hipSuccess) { free_wf(c); return e; }
     for (int j = 1; j < lanes; j++) {
         rt::WfBufs v = w;
-        v.rayO += slots * j; v.rayD += slots * j; v.hitA += slots * j; v.hitG += slots * j; v.accO += slots * j; v.accB += slots * j;
+        v.rayO += queueWords * j; v.rayD += queueWords * j; v.accO += queueWords * j; v.accB += queueWords * j;
+        v.hitA += (queueWords / 2) * j; v.hitG += (queueWords / 2) * j;
         v.out += slots * j; v.outRays += slots * j; v.pixFlag += slots * j; v.queue += queueWords * j; v.ctrl += ctrlWords * j;
         c->wf.bufs[j] = v;
     }

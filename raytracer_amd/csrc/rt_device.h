@@ -116,12 +116,14 @@ constexpr uint32_t kWfMiss = 0x0FFFFFFFu;  // hitG: no triangle
 constexpr uint32_t kWfDanger = 0x80000000u; // hitG flag: the pixel must be re-rendered by the exact kernel
 
 struct WfBufs {
-    float4* rayO;        // [slot] origin, maxDistance
-    float4* rayD;        // [slot] direction, RNG state
-    float4* hitA;        // [slot] t, b0, b1, b2 of the closest hit
-    uint32_t* hitG;      // [slot] gid | flags
-    float4* accO;        // [slot] outgoing light, checksum bits
-    float4* accB;        // [slot] beta accumulation
+    // per level, indexed by queue position (stripe, offset), ping-pong over levels like the queue:
+    // a level's shade launch reads its entries front to back and writes the survivors' next to each other
+    float4* rayO;        // [2][kWfStripes][subCap] origin, maxDistance
+    float4* rayD;        // [2][kWfStripes][subCap] direction, RNG state
+    float4* accO;        // [2][kWfStripes][subCap] outgoing light, checksum bits
+    float4* accB;        // [2][kWfStripes][subCap] beta accumulation
+    float4* hitA;        // [kWfStripes][subCap] t, b0, b1, b2 of the closest hit (trace -> shade of one level)
+    uint32_t* hitG;      // [kWfStripes][subCap] gid | flags
     float4* out;         // [slot] finished sample: exposure-corrected rgb, checksum bits
     uint8_t* outRays;    // [slot] closest-hit queries of the finished sample
     uint32_t* pixFlag;   // [pixelInChunk] != 0: flagged for the redo launch

@@ -757,9 +757,15 @@ __device__ __forceinline__ uint32_t* wf_cursor(const WfBufs& w, int level, int s
 {
     return w.ctrl + ((size_t)(level * 2 + 1) * kWfStripes + stripe) * kWfCtrlStride;
 }
-__device__ __forceinline__ uint32_t* wf_queue(const WfBufs& w, int level, int stripe)
+// position of entry `off` of a stripe at a level inside the ping-pong arrays (queue, rayO, rayD, accO, accB)
+__device__ __forceinline__ size_t wf_pos(const WfBufs& w, int level, uint32_t stripe, uint32_t off)
 {
-    return w.queue + ((size_t)(level & 1) * kWfStripes + stripe) * (size_t)w.subCap;
+    return ((size_t)(level & 1) * kWfStripes + stripe) * (size_t)w.subCap + off;
+}
+// ... and inside the single-buffered hit arrays
+__device__ __forceinline__ size_t wf_hit_pos(const WfBufs& w, uint32_t stripe, uint32_t off)
+{
+    return (size_t)stripe * (size_t)w.subCap + off;
 }
 // finished-sample results are stored sample-major inside each 64-pixel tile, so that wf_resolve's
 // lanes (one pixel each) read consecutive addresses
@@ -797,8 +803,8 @@ __global__ __launch_bounds__(256) void wf_gen_kernel(const RenderArgs a, const W
             uint32_t seed = sample_seed(a, x, y, sidx);
             const Ray ray = setup_ray(a, x, y, seed);
             if (a.bounceCount > 0) {
-                w.rayO[i] = make_float4(ray.ox, ray.oy, ray.oz, ray.maxDist);
-                w.rayD[i] = make_float4(ray.dx, ray.dy, ray.dz, __uint_as_float(seed));
+                w.rayO[wf_pos(w, 0, stripe, off)] = make_float4(ray.ox, ray.oy, ray.oz, ray.maxDist);
+                w.rayD[wf_pos(w, 0, stripe, off)] = make_float4(ray.dx, ray.dy, ray.dz, __uint_as_float(seed));
                 entry = i; // outgoing light 0, beta 1, checksum 0: wf_shade(0) supplies them
             } else { // the bounce loop does not run: radiance 0 (:172)
                 if (sidx == 0 && a.ids) {
@@ -811,7 +817,7 @@ __global__ __launch_bounds__(256) void wf_gen_kernel(const RenderArgs a, const W
             }
         }
     }
-    wf_queue(w, 0, (int)stripe)[off] = entry;
+    w.queue[wf_pos(w, 0, stripe, off)] = entry;
 }
 
 #ifndef RT_WF_OCC
@@ -829,72 +835,132 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
     uint32_t* slotx = poolSlot + (threadIdx.x & ~63);
     LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
 
+    // Work arrives in blocks of up to 64 consecutive queue entries of one stripe, claimed with one
+    // atomic.  Three blocks are in flight so that a refill never waits on memory: `cur` (in registers,
+    // handed out lane by lane), `nxt` (its loads issued at the previous promotion) and the pending
+    // claim (its atomic issued then too).  Measured before this: a third of the wave time of the
+    // level's launch went into the dependent chain atomic -> queue entry -> ray at refill time.
     const uint32_t waveId = blockIdx.x * 4u + (threadIdx.x >> 6);
-    uint32_t stripe = waveId % kWfStripes;
+    uint32_t stripe = waveId % kWfStripes, stripeCnt = 0;   // wave-uniform
     unsigned long long exhausted = 0ull, poolMask = 0ull;
-    uint32_t poolVal = kWfHole;
-    bool noMore = false, have = false;
-    uint32_t slot = 0;
+    bool pendIssued = false, nxtHas = false, noMore = false, have = false;
+    uint32_t pendC = 0;                 // lane 0: cursor value returned by the pending atomic
+    uint32_t cSlot = kWfHole, nSlot = kWfHole, cOff = 0, nOff = 0;   // nOff/cOff: hit-array position of the lane's entry
+    float4 cO = make_float4(0, 0, 0, 0), cD = cO, nO = cO, nD = cO;
+    uint32_t hitPos = 0;
     Ray ray; ray.ox = ray.oy = ray.oz = ray.dx = ray.dy = ray.dz = 0.0f; ray.maxDist = 0.0f;
     Trav T; trav_begin(T, a.scene, ray, stack); T.node = kTravEnd;
 
+    // picks the next stripe that still has entries (wave-uniform); false when none is left.  The count
+    // of the stripe in use stays cached: re-reading it would put a dependent fetch into every refill.
+    bool stripeOk = false;
+    auto pick_stripe = [&]() -> bool {
+        if (stripeOk && !(exhausted & (1ull << stripe))) return true;
+        for (int k = 0; k < kWfStripes; k++) {
+            const uint32_t sidx = (stripe + (uint32_t)k) % kWfStripes;
+            if (exhausted & (1ull << sidx)) continue;
+            const uint32_t cnt = *wf_count(w, level, (int)sidx);
+            if (cnt == 0u) { exhausted |= 1ull << sidx; continue; }
+            stripe = sidx; stripeCnt = cnt; stripeOk = true;
+            return true;
+        }
+        stripeOk = false;
+        return false;
+    };
+    auto issue_claim = [&]() {
+        pendIssued = pick_stripe();
+        if (pendIssued && lane == 0) pendC = atomicAdd(wf_cursor(w, level, (int)stripe), 64u);
+    };
+    // resolves the pending claim into (offset within the stripe, entries); claims again elsewhere when
+    // the stripe ran out meanwhile
+    auto resolve_claim = [&](uint32_t& off, uint32_t& n) -> bool {
+        while (pendIssued) {
+            const uint32_t c = (uint32_t)__shfl((int)pendC, 0);
+            if (c < stripeCnt) { off = c; n = stripeCnt - c < 64u ? stripeCnt - c : 64u; return true; }
+            exhausted |= 1ull << stripe;
+            issue_claim();
+        }
+        return false;
+    };
+    auto load_next = [&]() {
+        uint32_t off = 0, n = 0;
+        nxtHas = resolve_claim(off, n);
+        if (nxtHas) {
+            const size_t p = wf_pos(w, level, stripe, off + (uint32_t)lane);
+            const bool in = (uint32_t)lane < n;
+            nSlot = in ? w.queue[p] : kWfHole;
+            if (in) { nO = w.rayO[p]; nD = w.rayD[p]; }
+            nOff = (uint32_t)wf_hit_pos(w, stripe, off + (uint32_t)lane);
+            issue_claim();
+        }
+    };
+    issue_claim();
+    load_next();
+
     for (;;) {
+#ifdef RT_PHASE_TIMERS
+        const long long tq0 = clock64();
+#endif
         // ---- results of the lanes that finished
         if (have && !trav_running(T)) {
             bool danger = false;
             const Hit h = trav_result(T, ray, danger);
             if (stack.dropped) { danger = true; stack.dropped = false; }
             if (danger) st.slow++;
-            w.hitA[slot] = make_float4(h.t, h.b0, h.b1, h.b2);
-            w.hitG[slot] = (h.gid == kNoHit ? kWfMiss : h.gid) | (danger ? kWfDanger : 0u);
+            w.hitA[hitPos] = make_float4(h.t, h.b0, h.b1, h.b2);
+            w.hitG[hitPos] = (h.gid == kNoHit ? kWfMiss : h.gid) | (danger ? kWfDanger : 0u);
             have = false;
         }
-        // ---- refill from the queue
+#ifdef RT_PHASE_TIMERS
+        const long long tq1 = clock64();
+#endif
+        // ---- refill from the pool
         unsigned long long need = __ballot(!have && !noMore);
         while (need != 0ull) {
             if (poolMask == 0ull) {
-                int base = -1, n = 0;
-                if (lane == 0) {
-                    for (int k = 0; k < kWfStripes && base < 0; k++) {
-                        const uint32_t sidx = (stripe + (uint32_t)k) % kWfStripes;
-                        if (exhausted & (1ull << sidx)) continue;
-                        const uint32_t cnt = *wf_count(w, level, (int)sidx);
-                        const uint32_t c = cnt ? atomicAdd(wf_cursor(w, level, (int)sidx), 64u) : 0u;
-                        if (c < cnt) { base = (int)(sidx * w.subCap + c); n = (int)(cnt - c < 64u ? cnt - c : 64u); stripe = sidx; }
-                        else exhausted |= 1ull << sidx;
-                    }
-                }
-                base = __shfl(base, 0); n = __shfl(n, 0);
-                if (base < 0) { noMore = true; break; }
-                poolVal = lane < n ? (w.queue + (size_t)(level & 1) * kWfStripes * (size_t)w.subCap)[(uint32_t)base + (uint32_t)lane] : kWfHole;
-                poolMask = __ballot(poolVal != kWfHole);
+                if (!nxtHas) { noMore = true; break; }
+                cSlot = nSlot; cO = nO; cD = nD; cOff = nOff;
+                poolMask = __ballot(cSlot != kWfHole);
+                load_next();
                 if (poolMask == 0ull) continue;
             }
+            // the k-th needing lane takes the k-th live pool entry
             const unsigned long long below = (1ull << lane) - 1ull;
-            if ((poolMask >> lane) & 1ull) slotx[__popcll(poolMask & below)] = poolVal;
+            if ((poolMask >> lane) & 1ull) slotx[__popcll(poolMask & below)] = (uint32_t)lane;
             const int rank = __popcll(need & below);
             const int avail = __popcll(poolMask);
             const bool want = (need >> lane) & 1ull;
             __builtin_amdgcn_wave_barrier();
+            const int src = (want && rank < avail) ? (int)slotx[rank] : lane;
+            __builtin_amdgcn_wave_barrier();
+            const float ox = __shfl(cO.x, src), oy = __shfl(cO.y, src), oz = __shfl(cO.z, src), om = __shfl(cO.w, src);
+            const float dx = __shfl(cD.x, src), dy = __shfl(cD.y, src), dz = __shfl(cD.z, src);
+            const uint32_t hp = (uint32_t)__shfl((int)cOff, src);
             if (want && rank < avail) {
-                slot = slotx[rank];
-                const float4 o = w.rayO[slot], d = w.rayD[slot];
-                ray.ox = o.x; ray.oy = o.y; ray.oz = o.z; ray.maxDist = o.w; ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
+                ray.ox = ox; ray.oy = oy; ray.oz = oz; ray.maxDist = om; ray.dx = dx; ray.dy = dy; ray.dz = dz;
+                hitPos = hp;
                 trav_begin(T, a.scene, ray, stack);
                 have = true;
             }
-            __builtin_amdgcn_wave_barrier();
-            int k = __popcll(__ballot(want && rank < avail));
-            unsigned long long m = poolMask;
-            while (k-- > 0) m &= m - 1ull;
-            poolMask = m;
+            // the entries handed out are the pool's first popc(taken) live ones
+            const int taken = __popcll(__ballot(want && rank < avail));
+            poolMask = __ballot(((poolMask >> lane) & 1ull) && __popcll(poolMask & below) >= taken);
             need = __ballot(!have && !noMore);
         }
         if (__ballot(have) == 0ull) break;
         // ---- traversal burst
         const bool running = have && trav_running(T);
         const int nRun = __popcll(__ballot(running));
+#ifdef RT_PHASE_TIMERS
+        const long long tq2 = clock64();
+#endif
         if (running) trav_burst(T, a.scene, ray, stack, st.bvh, noMore ? 1 : (nRun * kKeepNum + kKeepDen - 1) / kKeepDen);
+#ifdef RT_PHASE_TIMERS
+        if (lane == 0) {
+            st.bvh.idleA += (uint32_t)((clock64() - tq2) >> 6); st.bvh.idleB += (uint32_t)((tq1 - tq0) >> 6);
+            st.bvh.diagA += (uint32_t)((tq2 - tq1) >> 6); st.slow++; st.bvh.diagB += (uint32_t)nRun;
+        }
+#endif
     }
     flush_stats(a, st, wgCnt);
 }
@@ -911,15 +977,19 @@ __global__ __launch_bounds__(256) void wf_shade_kernel(const RenderArgs a, const
         const uint32_t stripe = piece % kWfStripes, off = (piece / kWfStripes) * 256u + threadIdx.x;
         const uint32_t cnt = *wf_count(w, level, (int)stripe);
         if ((piece / kWfStripes) * 256u >= cnt) continue; // uniform per workgroup
-        const uint32_t slot = off < cnt ? wf_queue(w, level, (int)stripe)[off] : kWfHole;
+        const size_t pin = wf_pos(w, level, stripe, off), ph = wf_hit_pos(w, stripe, off);
+        const uint32_t slot = off < cnt ? w.queue[pin] : kWfHole;
         bool more = false;
+        Ray nray; nray.ox = nray.oy = nray.oz = nray.dx = nray.dy = nray.dz = nray.maxDist = 0.0f;
+        PathAcc nacc; nacc.ox = nacc.oy = nacc.oz = nacc.bx = nacc.by = nacc.bz = 0.0f;
+        uint32_t nseed = 0, nchk = 0;
         if (slot != kWfHole) {
             const uint32_t spp = a.sampleCount;
             const uint32_t pix = slot / spp, sidx = slot - pix * spp;
-            const float4 o = w.rayO[slot], d = w.rayD[slot], hA = w.hitA[slot];
-            const float4 aO = level == 0 ? make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u)) : w.accO[slot];
-            const float4 aB = level == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : w.accB[slot];
-            const uint32_t hG = w.hitG[slot];
+            const float4 o = w.rayO[pin], d = w.rayD[pin], hA = w.hitA[ph];
+            const float4 aO = level == 0 ? make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u)) : w.accO[pin];
+            const float4 aB = level == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : w.accB[pin];
+            const uint32_t hG = w.hitG[ph];
             Ray ray; ray.ox = o.x; ray.oy = o.y; ray.oz = o.z; ray.maxDist = o.w; ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
             uint32_t seed = __float_as_uint(d.w), checksum = __float_as_uint(aO.w);
             PathAcc acc; acc.ox = aO.x; acc.oy = aO.y; acc.oz = aO.z; acc.bx = aB.x; acc.by = aB.y; acc.bz = aB.z;
@@ -938,11 +1008,8 @@ __global__ __launch_bounds__(256) void wf_shade_kernel(const RenderArgs a, const
                 uint32_t* idp = reinterpret_cast<uint32_t*>(a.ids + ((size_t)y * (size_t)a.width + (size_t)x));
                 idp[0] = primary[0]; idp[1] = primary[1]; idp[2] = primary[2];
             }
-            if (more) {
-                w.rayO[slot] = make_float4(ray.ox, ray.oy, ray.oz, ray.maxDist);
-                w.rayD[slot] = make_float4(ray.dx, ray.dy, ray.dz, __uint_as_float(seed));
-                w.accO[slot] = make_float4(acc.ox, acc.oy, acc.oz, __uint_as_float(checksum));
-                w.accB[slot] = make_float4(acc.bx, acc.by, acc.bz, 0.0f);
+            if (more) { // kept in registers until the survivors' positions are known
+                nray = ray; nseed = seed; nchk = checksum; nacc = acc;
             } else { // exposureCorrection (:690-698), per sample
                 const size_t oi = wf_out_index(pix, sidx, spp);
                 w.out[oi] = make_float4(1.0f - rtd::exp_f(-acc.ox * a.exposure), 1.0f - rtd::exp_f(-acc.oy * a.exposure),
@@ -956,7 +1023,14 @@ __global__ __launch_bounds__(256) void wf_shade_kernel(const RenderArgs a, const
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(wf_count(w, level + 1, (int)stripe), (uint32_t)__popcll(mm));
             base = __shfl(base, 0);
-            if (more) wf_queue(w, level + 1, (int)stripe)[base + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = slot;
+            if (more) {
+                const size_t po = wf_pos(w, level + 1, stripe, base + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull)));
+                w.queue[po] = slot;
+                w.rayO[po] = make_float4(nray.ox, nray.oy, nray.oz, nray.maxDist);
+                w.rayD[po] = make_float4(nray.dx, nray.dy, nray.dz, __uint_as_float(nseed));
+                w.accO[po] = make_float4(nacc.ox, nacc.oy, nacc.oz, __uint_as_float(nchk));
+                w.accB[po] = make_float4(nacc.bx, nacc.by, nacc.bz, 0.0f);
+            }
         }
     }
     flush_stats(a, st, wgCnt);
