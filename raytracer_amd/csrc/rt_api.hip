@@ -13,6 +13,7 @@ namespace {
 constexpr size_t kWorkBytes = sizeof(uint32_t) * 512;
 constexpr size_t kWfChunkDefault = 64u << 20;
 constexpr size_t kWfLaneMin = 2u << 20;   // samples below which another lane is not worth its launches
+constexpr int kWfLanesDefault = 3;        // the process has 4 hardware queues and one carries the copies: a 4th lane shares a queue and serialises
 constexpr size_t kCntBytes = sizeof(unsigned long long) * rt::kCounterSlots * rt::kCounterStride;
 
 thread_local std::string g_createError;
@@ -61,7 +62,7 @@ struct rt_ctx {
     bool renderedOnce = false;
     float commitMs = 0.0f;
     int optTraversal = 0;
-    int optWfLanes = rt::kWfMaxLanes;
+    int optWfLanes = 0;                       // 0 = by scene size
     size_t optWfChunk = kWfChunkDefault;     // samples in flight per chunk of the wavefront pipeline
     rt::WfLanes wf; size_t wfCapSlots = 0; int wfLevels = 0; int wfLanes = 0; // its lanes and their workspace (wf.bufs[0] owns the allocations)
     int optCounters = 0;
@@ -303,7 +304,7 @@ int rt_set_option(rt_ctx* c, int option, int value)
         c->optTraversal = value; return RT_OK;
     case RT_OPT_WF_LANES:
         if (value < 0 || value > rt::kWfMaxLanes) return fail(c, RT_ERR_INVALID, "RT_OPT_WF_LANES takes 0 (default) .. 4");
-        c->optWfLanes = value ? value : rt::kWfMaxLanes; return RT_OK;
+        c->optWfLanes = value; return RT_OK;
     case RT_OPT_WF_CHUNK:
         if (value < 0) return fail(c, RT_ERR_INVALID, "RT_OPT_WF_CHUNK takes a sample count >= 0 (0 = default)");
         c->optWfChunk = value ? (size_t)value : kWfChunkDefault; return RT_OK;
@@ -719,7 +720,10 @@ int rt_render(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* 
         if (tiles > 0) {
             // lanes: one per kWfLaneMin samples up to optWfLanes; chunks: whole tiles, at most optWfChunk samples each
             int lanes = (int)((tiles * perTile) / kWfLaneMin);
-            lanes = lanes < 1 ? 1 : (lanes > c->optWfLanes ? c->optWfLanes : lanes);
+            // default: 3 lanes for large scenes, where the tails of the trace launches are long (C4 4 lanes 27.3 /
+            // 3 lanes 22.6 / 2 lanes 24.3 ms), 2 for small ones (C2 9.9 / 9.3 / 8.8 ms)
+            const int maxLanes = c->optWfLanes ? c->optWfLanes : (c->built.nTris >= (1u << 18) ? kWfLanesDefault : 2);
+            lanes = lanes < 1 ? 1 : (lanes > maxLanes ? maxLanes : lanes);
             size_t chunkTiles = (tiles + (size_t)lanes - 1) / (size_t)lanes;
             const size_t capTiles = c->optWfChunk / perTile ? c->optWfChunk / perTile : 1;
             if (chunkTiles > capTiles) chunkTiles = capTiles;

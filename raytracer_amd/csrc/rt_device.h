@@ -132,7 +132,8 @@ struct WfBufs {
     uint32_t subCap;
     uint32_t nSlots;
     uint32_t nPix;       // pixels of the chunk = tiles * 64 (edge tiles include pixels outside the rectangle)
-    uint32_t tileBegin;  // first tile of the chunk (tile index over the render rectangle, row-major)
+    uint32_t tileBegin;  // the chunk's tiles are tileBegin + i * tileStride (tile index over the render rectangle,
+    uint32_t tileStride; // row-major): chunks interleave, so that each gets the same mix of cheap and costly tiles
 };
 
 struct RenderArgs {

@@ -776,7 +776,7 @@ __device__ __forceinline__ size_t wf_out_index(uint32_t pix, uint32_t sidx, uint
 // slot -> pixel; false when the pixel lies outside the render rectangle (edge tiles)
 __device__ __forceinline__ bool wf_pixel(const RenderArgs& a, const WfBufs& w, uint32_t pix, int& x, int& y)
 {
-    const uint32_t tile = w.tileBegin + (pix >> 6), in = pix & 63u;
+    const uint32_t tile = w.tileBegin + (pix >> 6) * w.tileStride, in = pix & 63u;
     x = a.x0 + (int)(tile % (uint32_t)a.tiles8X) * 8 + (int)(in & 7u);
     y = a.y0 + (int)(tile / (uint32_t)a.tiles8X) * 8 + (int)(in >> 3);
     return x < a.x1 && y < a.y1;
@@ -1177,13 +1177,12 @@ void launch_render_wf(const RenderArgs& a, const WfLanes& L, int numCUs, hipStre
         const int j = (int)(k % (uint32_t)used);
         hipStream_t stream = j == 0 ? mainStream : L.streams[j];
         WfBufs w = L.bufs[j];
-        const uint32_t t0 = k * tilesPerChunk;
-        const uint32_t nt = nTiles - t0 < tilesPerChunk ? nTiles - t0 : tilesPerChunk;
-        w.tileBegin = t0; w.nPix = nt * 64u; w.nSlots = w.nPix * spp;
+        const uint32_t nt = (nTiles - k + nChunks - 1) / nChunks; // tiles k, k + nChunks, ...
+        w.tileBegin = k; w.tileStride = nChunks; w.nPix = nt * 64u; w.nSlots = w.nPix * spp;
         const uint32_t nPieces = (w.nSlots + 255u) / 256u;
         RenderArgs c = b;
         c.redoCount = w.ctrl + (ctrlWords - kWfCtrlStride);
-        c.redoList = b.redoList + (size_t)t0 * 64u;
+        c.redoList = b.redoList + (size_t)k * tilesPerChunk * 64u;
         hipMemsetAsync(w.ctrl, 0, sizeof(uint32_t) * ctrlWords, stream);
         hipLaunchKernelGGL(wf_gen_kernel, dim3(nPieces), dim3(256), 0, stream, c, w);
         uint32_t gridT = (uint32_t)numCUs * RT_WF_OCC;

@@ -14,8 +14,9 @@ rows=[r for r in csv.DictReader(open(t)) if "wf_" in r["Kernel_Name"]]
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 # last frame: the last len/7 launches
 n=len(rows)//7
+t0=int(rows[-n]["Start_Timestamp"])
 for r in rows[-n:]:
-    print("   %-40s %.3f ms" % (r["Kernel_Name"][:40], (int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6))
+    print("   %-28s q%-3s start %7.3f  dur %7.3f ms" % (r["Kernel_Name"][:28], r.get("Queue_Id","?"), (int(r["Start_Timestamp"])-t0)/1e6, (int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6))
 if rows[-n:]:
     print("   frame span %.3f ms" % ((int(rows[-1]["End_Timestamp"])-int(rows[-n]["Start_Timestamp"]))/1e6))
 PY
