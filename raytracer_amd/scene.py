@@ -351,8 +351,42 @@ class MeshObject(DisplayObject):
         self.meshes = list(meshes)
         self.materials = list(materials)
         self.isComposite = len(self.meshes) > 1
-        self.updateCompositeBounds()
+        if self.meshes:
+            self.updateCompositeBounds()
         self.loadSuccess = len(self.meshes) > 0
+
+
+class CustomModel(MeshObject):
+    """src/CustomModel.hpp / CustomModel.cpp:47-194: a model file turned into (Mesh, materialIndex)
+    pairs and Materials.  The importer is raytracer_amd.assets (COLLADA, OBJ/MTL, binary FBX) in
+    place of assimp; its flattening rules, and why parity with assimp's is unpinned, are stated
+    there.  As in the reference, a file that cannot be read gives getLoadSuccess() == False rather
+    than an exception, textures are looked up next to the asset (or next to its "source"
+    directory, :110-112), and a texture that fails to load leaves the material's constant."""
+
+    def __init__(self, path, position=DEFAULT_POSITION, rotation=DEFAULT_ROTATION, scale=DEFAULT_SCALE):
+        from . import assets
+
+        self.path = str(path)
+        meshes, materials = [], []
+        try:
+            asset = assets.load_asset(self.path)
+            directory = asset.texture_directory()
+            for fm in asset.materials:
+                m = Material(fm.name)
+                setters = {"albedo": m.setAlbedoTexture, "normal": m.setNormalTexture, "roughness": m.setRoughnessTexture,
+                           "metal": m.setMetalTexture, "ao": m.setAmbientOcclusionTexture, "emission": m.setEmissionTexture}
+                for role, rel in fm.textures.items():
+                    if rel:
+                        setters[role]((directory + "/" + rel).replace("\\", "/"))
+                materials.append(m)
+            for fmesh in asset.meshes:
+                if fmesh.indices.shape[0] == 0:
+                    continue
+                meshes.append((Mesh(fmesh.positions, fmesh.indices, fmesh.uvs, fmesh.normals), int(fmesh.material)))
+        except Exception:
+            meshes, materials = [], []
+        super().__init__(meshes, materials, position, rotation, scale)
 
 
 @dataclass
