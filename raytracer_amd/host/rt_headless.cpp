@@ -30,6 +30,23 @@ int main(int argc, char** argv)
         dump("rays", rays.data(), rays.size());
         return 0;
     }
+    if (argc >= 3 && std::string(argv[1]) == "asset") {
+        // flatten a model file and print what came out: per mesh the sizes and a CRC of every array
+        // (tests/test_host_cpp.py compares them with raytracer_amd/assets.py); no device involved
+        assets::FlatAsset a;
+        if (!assets::loadAsset(argv[2], a)) { printf("load failed\n"); return 3; }
+        printf("meshes %zu materials %zu triangles %zu texdir %s\n", a.meshes.size(), a.materials.size(), a.triangleCount(), a.textureDirectory().c_str());
+        auto crc = [](const void* p, size_t n) { return (unsigned long)crc32(0L, (const Bytef*)p, (uInt)n); };
+        for (auto& m : a.meshes)
+            printf("mesh %zu %zu %d %lu %lu %lu %lu\n", m.positions.size() / 3, m.indices.size() / 3, m.material, crc(m.positions.data(), m.positions.size() * 4),
+                   crc(m.indices.data(), m.indices.size() * 4), crc(m.uvs.data(), m.uvs.size() * 4), crc(m.normals.data(), m.normals.size() * 4));
+        for (auto& m : a.materials) {
+            printf("material %s", m.name.c_str());
+            for (auto& t : m.textures) printf(" %s=%s", t.first.c_str(), t.second.c_str());
+            printf("\n");
+        }
+        return 0;
+    }
     if (argc >= 8 && std::string(argv[1]) == "render") {
         try {
             const int W = atoi(argv[4]), H = atoi(argv[5]), spp = atoi(argv[6]), depth = atoi(argv[7]);

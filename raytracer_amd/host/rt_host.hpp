@@ -9,6 +9,7 @@
 #include "../../include/rt_api.h"
 
 #include <zlib.h>
+#include "rt_assets.hpp"
 
 #include <algorithm>
 #include <cfloat>
@@ -398,6 +399,47 @@ public:
         isComposite = meshes.size() > 1;
         if (!meshes.empty()) { updateCompositeBounds(); loadSuccess = true; }
     }
+};
+
+// ---------------------------------------------------------------- CustomModel (CustomModel.hpp, CustomModel.cpp:47-194)
+// A model file turned into (Mesh, materialIndex) pairs and Materials by the native flatteners of
+// rt_assets.hpp (COLLADA, OBJ/MTL, binary FBX) in place of assimp.  A file that cannot be read gives
+// getLoadSuccess() == false; textures are looked up next to the asset, or next to its "source"
+// directory (:110-112); a texture that fails to load leaves the material's constant (the bool
+// convention of setOutputTexture, :76-101).  This host mirror decodes PNG only.
+class CustomModel : public MeshObject {
+public:
+    CustomModel(Device& dev, const std::string& path, vec3 position = {}, quat rotation = {}, vec3 scl = { 1, 1, 1 })
+        : MeshObject(dev, {}, {}, position, rotation, scl), path_(path)
+    {
+        assets::FlatAsset a;
+        if (!assets::loadAsset(path, a)) return;
+        const std::string dir = a.textureDirectory();
+        for (auto& fm : a.materials) {
+            auto m = std::make_shared<Material>(dev, fm.name.c_str());
+            for (auto& t : fm.textures) {
+                if (t.second.empty()) continue;
+                const std::string p = dir + "/" + t.second;
+                if (t.first == "albedo") m->setAlbedoTexture(p.c_str());
+                else if (t.first == "normal") m->setNormalTexture(p.c_str());
+                else if (t.first == "roughness") m->setRoughnessTexture(p.c_str());
+                else if (t.first == "metal") m->setMetalTexture(p.c_str());
+                else if (t.first == "ao") m->setAmbientOcclusionTexture(p.c_str());
+                else if (t.first == "emission") m->setEmissionTexture(p.c_str());
+            }
+            m->sendToGPU();
+            materials.push_back(m);
+        }
+        for (auto& fm : a.meshes) {
+            if (fm.indices.empty()) continue;
+            meshes.emplace_back(std::make_shared<Mesh>(dev, fm.positions, fm.indices, fm.uvs, fm.normals), fm.material);
+        }
+        isComposite = meshes.size() > 1;
+        if (!meshes.empty()) { updateCompositeBounds(); loadSuccess = true; }
+    }
+    std::string getPath() const { return path_; }
+private:
+    std::string path_;
 };
 
 // ---------------------------------------------------------------- Scene (Scene.hpp:41-176, Scene.cpp:3-29); iteration = insertion order

@@ -38,3 +38,55 @@ def test_cpp_host_renders_the_golden_frame(tmp_path):
     from PIL import Image
     im = np.asarray(Image.open(png))
     assert im.shape == (64, 64, 4) and tuple(im[0, 0, :3]) == (104, 104, 139)  # sky, top-left after the flip
+
+
+def _cpp_asset(path):
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(EXE)])
+    p = subprocess.run([EXE, "asset", path], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    return p.stdout.splitlines()
+
+
+def _compare_with_python(path):
+    """rt_assets.hpp against raytracer_amd/assets.py: sizes, material slots and a CRC of every array."""
+    import zlib
+    from raytracer_amd import assets
+    a = assets.load_asset(path)
+    out = _cpp_asset(path)
+    head = out[0].split()
+    assert (int(head[1]), int(head[3]), int(head[5])) == (len(a.meshes), len(a.materials), a.triangle_count)
+    assert head[7] == a.texture_directory()
+    for line, m in zip([l for l in out if l.startswith("mesh ")], a.meshes):
+        f = line.split()
+        crc = lambda x: zlib.crc32(np.ascontiguousarray(x).tobytes()) & 0xFFFFFFFF
+        nrm = m.normals if m.normals is not None else np.zeros(0, np.float32)
+        assert [int(v) for v in f[1:]] == [m.positions.shape[0], m.indices.shape[0], m.material, crc(m.positions), crc(m.indices),
+                                         crc(m.uvs), crc(nrm)], (path, line)
+    for line, m in zip([l for l in out if l.startswith("material ")], a.materials):
+        f = line.split(" ", 2)
+        assert f[1] == m.name.split(" ")[0] or line[len("material "):].startswith(m.name)
+        for role, tex in m.textures.items():
+            assert f"{role}={tex}" in line
+
+
+def test_cpp_asset_flatteners_match_python(tmp_path):
+    import test_assets as ta
+    ta.write_fbx(str(tmp_path / "m.fbx"))
+    _compare_with_python(str(tmp_path / "m.fbx"))
+    # OBJ with an MTL (texture names with blanks and options) and relative indices
+    (tmp_path / "m.mtl").write_text("newmtl skin\nKd 0.2 0.4 0.6\nmap_Kd tex/a b.png\nmap_Bump -bm 1.0 tex/n.png\n")
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0.5\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 0.25\nvn 0 0 1\n"
+                                    "usemtl skin\nf 1/1/1 2/2/1 3/3/1 4/4/1\nusemtl bare\nf -4 -3 -2\n")
+    _compare_with_python(str(tmp_path / "m.obj"))
+    assert _cpp_asset(str(tmp_path / "m.obj"))[-2].startswith("material skin albedo=tex/a b.png normal=tex/n.png")
+    bad = tmp_path / "bad.dae"
+    bad.write_text("<COLLADA><library_geometries>")
+    p = subprocess.run([EXE, "asset", str(tmp_path / "missing.fbx")], capture_output=True, text=True)
+    assert p.returncode == 3
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/res"), reason="reference checkout absent (it is on the GPU box)")
+def test_cpp_asset_flatteners_on_reference_files():
+    _compare_with_python("/root/reference/res/lowpolypbrtrash/source/model.dae")
+    _compare_with_python("/root/reference/res/pbrsword/source/murasama.fbx")

@@ -376,3 +376,25 @@ def test_larger_configs_against_oracle(ctx, name, args, rect):
         assert np.array_equal(ids[y0:y1, x0:x1], rid[y0:y1, x0:x1])
         assert np.array_equal(img[y0:y1, x0:x1], ref[y0:y1, x0:x1], equal_nan=True)
         assert (rid[y0:y1, x0:x1, 0] != 0xFFFFFFFF).any()
+
+
+def test_custom_model_from_asset_files(ctx, tmp_path):
+    """A CustomModel flattened from model files written here (binary FBX + OBJ) renders like the oracle
+    in all three modes (the flatteners feed the same upload path)."""
+    import test_assets as ta
+    from raytracer_amd.scene import CustomModel
+    ta.write_fbx(str(tmp_path / "m.fbx"))
+    (tmp_path / "q.obj").write_text("v -2 -1 -1\nv 2 -1 -1\nv 2 -1 3\nv -2 -1 3\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nvn 0 1 0\n"
+                                    "f 1/1/1 2/2/1 3/3/1 4/4/1\n")
+    sc = Scene()
+    a = CustomModel(str(tmp_path / "m.fbx"), position=(-1.0, -0.5, 0.0), scale=(1.2, 1.2, 1.2))
+    b = CustomModel(str(tmp_path / "q.obj"))
+    assert a.getLoadSuccess() and b.getLoadSuccess()
+    sc.addToScene("fbx", a)
+    sc.addToScene("floor", b)
+    cam = Camera(position=(0.5, 1.5, 6.0), fov=45.0)
+    cam.setWidth(96); cam.setHeight(64); cam.calcRays()
+    st = RenderSettings(sampleCount=3, bounceCount=3)
+    _, rid, _ = compare_modes(ctx, sc.flatten(), cam, st)
+    # the floor is flat, hence invisible (object-space cull with strict <, SURVEY 8a-Q4): only the FBX model is hit
+    assert (rid[..., 0] != 0xFFFFFFFF).mean() > 0.05 and not (rid[..., 0] == 1).any()
