@@ -523,8 +523,7 @@ int rt_scene_commit(rt_ctx* c, const rt_id* objects, const float* model16, const
     }
     if (total >= (1ull << 28)) return fail(c, RT_ERR_INVALID, "scene exceeds 2^28 triangles");
 
-    // tables
-    rt::free_scene(c->built);
+    // tables (the record arrays and the build's scratch arena in c->built are kept for the re-commit)
     c->committed = false;
     hipFree(c->dObjects); c->dObjects = nullptr; c->nObjects = 0;
     hipFree(c->dMaterials); c->dMaterials = nullptr; c->capMaterials = 0;

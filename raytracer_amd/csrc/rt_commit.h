@@ -30,6 +30,11 @@ struct BuiltScene {
     uint32_t nTris = 0;
     uint32_t nNodes = 0;
     float sceneMaxAbs = 0.0f;
+    // kept across commits (dynamic scenes re-commit every frame, Scene.cpp:3-29): the record arrays
+    // while the triangle count fits, and one arena for every scratch array of the build
+    uint32_t capTris = 0;
+    void* arena = nullptr;
+    size_t arenaBytes = 0;
 };
 
 bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t nTris, BuiltScene& out,

@@ -427,33 +427,56 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
     out.sceneMaxAbs = 0.0f;
     if (nTris == 0) return true;
     const uint32_t grid = (nTris + 255) / 256;
-
-    RT_HIP(hipMalloc((void**)&out.triRef, sizeof(TriIsect) * (size_t)nTris));
-    RT_HIP(hipMalloc((void**)&out.triLeaf, 3 * sizeof(TriIsect) * (size_t)nTris));
-    RT_HIP(hipMalloc((void**)&out.triShade, sizeof(TriShade) * (size_t)nTris));
     const uint32_t nInternal = nTris > 1 ? nTris - 1 : 1;
-    RT_HIP(hipMalloc((void**)&out.nodes, sizeof(BvhNode) * (size_t)nInternal));
+
+    if (nTris > out.capTris) {
+        hipFree(out.triRef); hipFree(out.triLeaf); hipFree(out.triShade); hipFree(out.nodes);
+        out.triRef = nullptr; out.triLeaf = nullptr; out.triShade = nullptr; out.nodes = nullptr; out.capTris = 0;
+        RT_HIP(hipMalloc((void**)&out.triRef, sizeof(TriIsect) * (size_t)nTris));
+        RT_HIP(hipMalloc((void**)&out.triLeaf, 3 * sizeof(TriIsect) * (size_t)nTris));
+        RT_HIP(hipMalloc((void**)&out.triShade, sizeof(TriShade) * (size_t)nTris));
+        RT_HIP(hipMalloc((void**)&out.nodes, sizeof(BvhNode) * (size_t)nInternal));
+        out.capTris = nTris;
+    }
     out.nNodes = nInternal;
 
-    // scratch
+    // scratch: carved out of one arena that survives the commit (a re-commit of a scene of the same
+    // size allocates nothing)
     uint32_t *dBounds = nullptr, *valsA = nullptr, *valsB = nullptr, *done = nullptr, *remaining = nullptr;
     unsigned long long *keysA = nullptr, *keysB = nullptr;
     int2 *queueA = nullptr, *queueB = nullptr;
     float* boxes = nullptr;
     int2 *children = nullptr, *ranges = nullptr;
     void* sortTmp = nullptr;
-    auto cleanup = [&]() {
-        hipFree(dBounds); hipFree(keysA); hipFree(keysB); hipFree(valsA); hipFree(valsB); hipFree(done);
-        hipFree(remaining); hipFree(boxes); hipFree(children); hipFree(ranges); hipFree(sortTmp);
-        hipFree(queueA); hipFree(queueB);
-    };
+    auto cleanup = [&]() {};
 #define RT_HIPC(call)                                                                                        \
     do {                                                                                                     \
         hipError_t e_ = (call);                                                                              \
         if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); cleanup(); return false; } \
     } while (0)
 
-    RT_HIPC(hipMalloc((void**)&dBounds, 6 * sizeof(uint32_t)));
+    size_t tmpBytes = 0;
+    RT_HIPC(rocprim::radix_sort_pairs(nullptr, tmpBytes, keysA, keysB, valsA, valsB, (size_t)nTris, 0, 63, stream));
+    {
+        const size_t n = nTris, ni = nInternal;
+        size_t off = 0;
+        auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+        const size_t oBounds = take(6 * sizeof(uint32_t)), oKeysA = take(8 * n), oKeysB = take(8 * n), oValsA = take(4 * n),
+                     oValsB = take(4 * n), oSort = take(tmpBytes ? tmpBytes : 16), oBoxes = take(sizeof(float) * 6 * 2 * n),
+                     oChildren = take(sizeof(int2) * ni), oRanges = take(sizeof(int2) * ni), oDone = take(4 * ni),
+                     oRemaining = take(4), oQueueA = take(sizeof(int2) * ni), oQueueB = take(sizeof(int2) * ni);
+        if (off > out.arenaBytes) {
+            hipFree(out.arena); out.arena = nullptr; out.arenaBytes = 0;
+            RT_HIP(hipMalloc(&out.arena, off));
+            out.arenaBytes = off;
+        }
+        char* base = (char*)out.arena;
+        dBounds = (uint32_t*)(base + oBounds); keysA = (unsigned long long*)(base + oKeysA); keysB = (unsigned long long*)(base + oKeysB);
+        valsA = (uint32_t*)(base + oValsA); valsB = (uint32_t*)(base + oValsB); sortTmp = base + oSort; boxes = (float*)(base + oBoxes);
+        children = (int2*)(base + oChildren); ranges = (int2*)(base + oRanges); done = (uint32_t*)(base + oDone);
+        remaining = (uint32_t*)(base + oRemaining); queueA = (int2*)(base + oQueueA); queueB = (int2*)(base + oQueueB);
+    }
+
     const uint32_t hb[6] = { host_f2o(FLT_MAX), host_f2o(FLT_MAX), host_f2o(FLT_MAX),
                              host_f2o(-FLT_MAX), host_f2o(-FLT_MAX), host_f2o(-FLT_MAX) };
     RT_HIPC(hipMemcpyAsync(dBounds, hb, sizeof(hb), hipMemcpyHostToDevice, stream));
@@ -471,19 +494,11 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
     }
     out.sceneMaxAbs = maxAbs;
 
-    RT_HIPC(hipMalloc((void**)&keysA, sizeof(unsigned long long) * (size_t)nTris));
-    RT_HIPC(hipMalloc((void**)&keysB, sizeof(unsigned long long) * (size_t)nTris));
-    RT_HIPC(hipMalloc((void**)&valsA, sizeof(uint32_t) * (size_t)nTris));
-    RT_HIPC(hipMalloc((void**)&valsB, sizeof(uint32_t) * (size_t)nTris));
     hipLaunchKernelGGL(morton_kernel, dim3(grid), dim3(256), 0, stream, out.triRef, nTris, dBounds, keysA, valsA);
     RT_HIPC(hipGetLastError());
 
-    size_t tmpBytes = 0;
-    RT_HIPC(rocprim::radix_sort_pairs(nullptr, tmpBytes, keysA, keysB, valsA, valsB, (size_t)nTris, 0, 63, stream));
-    RT_HIPC(hipMalloc(&sortTmp, tmpBytes ? tmpBytes : 16));
     RT_HIPC(rocprim::radix_sort_pairs(sortTmp, tmpBytes, keysA, keysB, valsA, valsB, (size_t)nTris, 0, 63, stream));
 
-    RT_HIPC(hipMalloc((void**)&boxes, sizeof(float) * 6 * (size_t)(2 * (size_t)nTris)));
     hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(256), 0, stream, out.triRef, valsB, nTris, out.triLeaf, boxes);
     RT_HIPC(hipGetLastError());
 
@@ -498,10 +513,6 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
 
     const int nInt = (int)nTris - 1;
     const uint32_t gridI = ((uint32_t)nInt + 255) / 256;
-    RT_HIPC(hipMalloc((void**)&children, sizeof(int2) * (size_t)nInt));
-    RT_HIPC(hipMalloc((void**)&ranges, sizeof(int2) * (size_t)nInt));
-    RT_HIPC(hipMalloc((void**)&done, sizeof(uint32_t) * (size_t)nInt));
-    RT_HIPC(hipMalloc((void**)&remaining, sizeof(uint32_t)));
     RT_HIPC(hipMemsetAsync(done, 0, sizeof(uint32_t) * (size_t)nInt, stream));
     hipLaunchKernelGGL(karras_kernel, dim3(gridI), dim3(256), 0, stream, keysB, (int)nTris, children, ranges);
     RT_HIPC(hipGetLastError());
@@ -522,8 +533,6 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
     if (!fitted) { err = "BVH box fit did not converge in 128 passes"; cleanup(); return false; }
 
     // collapse: `remaining` doubles as the next level's task count, done[0] as the node allocator
-    RT_HIPC(hipMalloc((void**)&queueA, sizeof(int2) * (size_t)nInt));
-    RT_HIPC(hipMalloc((void**)&queueB, sizeof(int2) * (size_t)nInt));
     const int2 rootTask = make_int2(0, 0);
     const uint32_t one = 1;
     RT_HIPC(hipMemcpyAsync(queueA, &rootTask, sizeof(rootTask), hipMemcpyHostToDevice, stream));
@@ -550,7 +559,7 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
 
 void free_scene(BuiltScene& s)
 {
-    hipFree(s.triRef); hipFree(s.triLeaf); hipFree(s.triShade); hipFree(s.nodes);
+    hipFree(s.triRef); hipFree(s.triLeaf); hipFree(s.triShade); hipFree(s.nodes); hipFree(s.arena);
     s = BuiltScene();
 }
 
