@@ -718,7 +718,9 @@ int rt_render(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* 
         if (perTile >= (1ull << 31)) return fail(c, RT_ERR_INVALID, "sampleCount too large for one 8x8 tile of the wavefront workspace");
         if (tiles > 0) {
             // lanes: one per kWfLaneMin samples up to optWfLanes; chunks: whole tiles, at most optWfChunk samples each
-            int lanes = (int)((tiles * perTile) / kWfLaneMin);
+            // (an explicit RT_OPT_WF_LANES is taken as given, up to one lane per tile)
+            int lanes = c->optWfLanes ? (int)(tiles < (size_t)c->optWfLanes ? tiles : (size_t)c->optWfLanes)
+                                      : (int)((tiles * perTile) / kWfLaneMin);
             // default: 3 lanes for large scenes, where the tails of the trace launches are long (C4 4 lanes 27.3 /
             // 3 lanes 22.6 / 2 lanes 24.3 ms), 2 for small ones (C2 9.9 / 9.3 / 8.8 ms)
             const int maxLanes = c->optWfLanes ? c->optWfLanes : (c->built.nTris >= (1u << 18) ? kWfLanesDefault : 2);

@@ -428,3 +428,33 @@ def test_dynamic_scene_recommit_matches_oracle(ctx):
         assert np.array_equal(img, ref)
     print("commit ms: first %.2f, re-commit %.2f" % (first_ms, ctx.stats().commit_ms))
     ctx.framebuffer_destroy(fb)
+
+
+@pytest.mark.parametrize("lanes,chunk", [(1, 1024), (3, 2048), (4, 1 << 20)])
+def test_wavefront_chunks_and_lanes(ctx, lanes, chunk):
+    """The wavefront pipeline cut into many chunks over several HIP streams (the sizes a small test frame
+    would never reach by itself): same pixels, ids and query count as the oracle, ragged edge tiles included."""
+    sc, cam = pbr_scene(seed=7, n_obj=16)
+    cam.setWidth(203); cam.setHeight(117); cam.calcRays()
+    st = RenderSettings(bounceCount=4, sampleCount=5, frameCount=3)
+    flat = sc.flatten()
+    ref, rid, nq = orc.render(flat, cam, st)
+    ctx.set_option(capi.OPT_WF_LANES, lanes)
+    ctx.set_option(capi.OPT_WF_CHUNK, chunk)
+    try:
+        img, ids, stats = render_gpu(ctx, flat, cam, st, 0)
+        check(ref, rid, nq, img, ids, stats)
+        assert np.array_equal(img, ref)
+        # a sub-rectangle with odd bounds on top of a previous frame (progressive mean)
+        rect = (13, 9, 150, 101)
+        st.progressiveFrameCount = 2
+        prev = np.random.default_rng(1).random((cam.height, cam.width, 4)).astype(np.float32)
+        ref2, rid2, nq2 = orc.render(flat, cam, st, rect=rect, prev=prev)
+        img2, ids2, stats2 = render_gpu(ctx, flat, cam, st, 0, rect=rect, prev=prev)
+        x0, y0, x1, y1 = rect
+        assert np.array_equal(img2[y0:y1, x0:x1], ref2[y0:y1, x0:x1]) and stats2.rays == nq2
+        assert np.array_equal(ids2[y0:y1, x0:x1], rid2[y0:y1, x0:x1])
+        assert np.array_equal(img2[:y0], prev[:y0]) and np.array_equal(img2[:, x1:], prev[:, x1:])
+    finally:
+        ctx.set_option(capi.OPT_WF_LANES, 0)
+        ctx.set_option(capi.OPT_WF_CHUNK, 0)
