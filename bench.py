@@ -219,7 +219,10 @@ def main():
         }
         if not args.no_cpu_baseline:
             from oracle import oracle_py as orc
-            c = min(args.cpu_crop, W, H)
+            # bounded sample: the oracle is brute force (every ray tests every triangle of every object it does
+            # not cull), so the crop shrinks with the scene to keep the CPU leg around 10-30 s
+            budget = 2.2e10
+            c = int(min(args.cpu_crop, W, H, max(8.0, (budget / (st.sampleCount * 1.8 * max(1, int(s.triangles)))) ** 0.5)))
             x0, y0 = (W - c) // 2, (H - c) // 2
             st.frameCount = args.warmup * (world if args.mode == "frames" else 1)
             st.progressiveFrameCount = 0
