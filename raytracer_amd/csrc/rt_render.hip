@@ -1,18 +1,17 @@
-// rt_render.hip -- the per-pixel render kernel for gfx950 (wave64).
+// rt_render.hip -- the render kernels for gfx950 (wave64).
 //
 // Replaces raytraceKernel and everything it inlines (processor/GPU/GPURaytracer.cu:78-885) plus
 // the GPUMaterial getters (Material.cu:268-323).  Result semantics follow the reference line by
-// line (each device function cites it); the execution shape does not:
-//  * a wavefront owns a compact pixel tile (8x8, 8x4 or 4x4 pixels) times 1, 2 or 4 sample lanes,
-//    chosen from sampleCount so that no lane is idle at 1 spp (the reference always launches
-//    4 z-lanes per pixel and parks three of them at 1 spp);
-//  * the reference's shared-memory reduction over the z lanes becomes a wave shuffle in the same
-//    summation order;
-//  * workgroup ids are remapped so that the workgroups sharing an XCD (and its 4 MiB L2) render
-//    one contiguous band of the tile;
-//  * geometry comes from the flattened world-space records of rt_device.h, through a BVH;
-//  * gfx950 has no texture unit: bilinear filtering is done in software on RGBA8 texels
-//    (value = byte/255.0f at fetch, the reference's own conversion, Material.cu:203).
+// line (each device function cites it); the execution shape does not.  Three pipelines share the
+// device functions of the first half of this file:
+//  * wavefront (default): wf_gen / wf_trace + wf_shade per bounce level / wf_resolve / wf_redo over
+//    path state kept in HBM, several chunks of the frame in flight on their own HIP streams;
+//  * path_kernel: one persistent kernel, lane = pixel, path regeneration (RT_OPT_TRAVERSAL = 2);
+//  * render_kernel<LOG2L, MODE>: one thread per (pixel, z lane) with the reference's nested loops --
+//    brute force in reference order (MODE 1) and the persistent kernel's redo launch (MODE 2).
+// Geometry comes from the flattened world-space records of rt_device.h, through a four-wide BVH
+// (rt_trace.h).  gfx950 has no texture unit: bilinear filtering is done in software on RGBA8 texels
+// (value = byte/255.0f at fetch, the reference's own conversion, Material.cu:203).
 #include "rt_trace.h"
 #include "rt_commit.h"
 
@@ -240,7 +239,6 @@ struct LaneStats {
     BvhCounters bvh;
 };
 
-// MODE 0: BVH, rays inside the tie band only raise `danger` (hot kernel)
 // MODE 1: brute force in reference order
 // MODE 2 / 3: BVH with the exact in-order emulation inline for rays inside the tie band
 //             (redo launch / rt_trace_rays)
@@ -249,8 +247,8 @@ __device__ __forceinline__ Hit closest_hit(const SceneView& s, Ray& ray, Stack& 
 {
     st.rays++;
     if (MODE == 1) return trace_brute(s, ray, st.triBrute);
-    if (MODE == 2 || MODE == 3) return trace_bvh<true>(s, ray, stack, st.bvh, st.slow, danger);
-    return trace_bvh<false>(s, ray, stack, st.bvh, st.slow, danger);
+    static_assert(MODE >= 1 && MODE <= 3, "closest_hit: MODE 1 (brute force) or 2 / 3 (BVH, exact)");
+    return trace_bvh(s, ray, stack, st.bvh, st.slow, danger);
 }
 
 struct PathAcc {

@@ -491,10 +491,10 @@ __device__ __noinline__ Hit trace_bvh_exact(const SceneView& s, Ray& ray, const 
     return best;
 }
 
-// EXACT = true: rays inside the band take trace_bvh_exact inline (rt_trace_rays, small kernels).
-// EXACT = false: the hot render kernel only reports `danger`; the pixel is re-rendered by the
-// redo launch, which keeps the rare path (and its registers) out of the hot kernel.
-template <bool EXACT>
+// Closest hit with the exact in-order emulation inline for rays inside the tie band (rt_trace_rays,
+// redo launches).  The hot kernels use the resumable traversal below instead, which only reports
+// `danger`: the pixel is then re-rendered by a redo launch, which keeps the rare path (and its
+// registers) out of them.
 __device__ __forceinline__ Hit trace_bvh(const SceneView& s, Ray& ray, Stack& stack, BvhCounters& cnt,
                                          uint32_t& slowPath, bool& danger)
 {
@@ -532,8 +532,7 @@ __device__ __forceinline__ Hit trace_bvh(const SceneView& s, Ray& ray, Stack& st
     const float limit = best.t + band_of(best.t, rayScale);
     if (otherT <= limit) {
         slowPath++;
-        if (EXACT) return trace_bvh_exact(s, ray, q, br, __builtin_fminf(limit, m0), stack, cnt);
-        danger = true;
+        return trace_bvh_exact(s, ray, q, br, __builtin_fminf(limit, m0), stack, cnt);
     }
     ray.maxDist = best.t;
     return best;
@@ -686,17 +685,6 @@ __device__ __forceinline__ Hit trav_finish(Trav& T, const SceneView& s, Ray& ray
         if (!object_cull_pass(T.cc.tmin, T.cc.bfar, T.m0)) danger = true;
     }
     return trav_result(T, ray, danger);
-}
-
-// the reference loop itself with the BVH used for culling only: every object with an accepted hit,
-// in index order (redo launch)
-__device__ __forceinline__ Hit trace_bvh_exact_all(const SceneView& s, Ray& ray, Stack& stack, BvhCounters& cnt)
-{
-    Hit none; none.t = FLT_MAX; none.gid = kNoHit; none.b0 = none.b1 = none.b2 = 0.0f;
-    if (!s.rootIsValid) return none;
-    const TriRay q = make_tri_ray(ray);
-    const BoxRay br = make_box_ray(ray, s.sceneMaxAbs);
-    return trace_bvh_exact(s, ray, q, br, ray.maxDist, stack, cnt);
 }
 
 } // namespace rt
