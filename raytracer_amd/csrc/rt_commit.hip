@@ -128,17 +128,15 @@ __global__ __launch_bounds__(256) void flatten_kernel(const Segment* __restrict_
     }
 }
 
-// spreads the low 21 bits of v so that two zero bits follow each of them
-__device__ __forceinline__ unsigned long long expand_bits21(uint32_t v)
-{
-    unsigned long long x = v & 0x1FFFFFull;
-    x = (x | (x << 32)) & 0x001F00000000FFFFull;
-    x = (x | (x << 16)) & 0x001F0000FF0000FFull;
-    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
-    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
-    x = (x | (x << 2)) & 0x1249249249249249ull;
-    return x;
-}
+// Extended Morton code (after Vaidyanathan et al. 2016): the 63 key bits are not handed to x, y, z
+// strictly in turn; an axis whose cell is already thin compared with the longest one sits its turn
+// out (build_scene).  A flat scene (a terrain is 400 x 13 x 400 units) otherwise spends every third
+// split on slabs that are already thin: C5 32.6 -> 18.0 node visits per ray, C4 19.0 -> 15.6.
+// `plan` holds the axis of every bit, most significant first, two bits each.
+#ifndef RT_MORTON_THIN
+#define RT_MORTON_THIN 0.25f
+#endif
+struct MortonPlan { unsigned long long lo, hi; };   // bits 0..31 in lo, 32..62 in hi
 
 __device__ __forceinline__ void tri_box(const TriIsect& t, float* mn, float* mx)
 {
@@ -148,7 +146,7 @@ __device__ __forceinline__ void tri_box(const TriIsect& t, float* mn, float* mx)
 }
 
 __global__ __launch_bounds__(256) void morton_kernel(const TriIsect* __restrict__ triRef, uint32_t nTris,
-                                                     const uint32_t* __restrict__ bounds,
+                                                     const uint32_t* __restrict__ bounds, MortonPlan plan,
                                                      unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -159,12 +157,24 @@ __global__ __launch_bounds__(256) void morton_kernel(const TriIsect* __restrict_
     tri_box(triRef[g], mn, mx);
     const float cx = 0.5f * (mn[0] + mx[0]), cy = 0.5f * (mn[1] + mx[1]), cz = 0.5f * (mn[2] + mx[2]);
     float fx = ex > 0.0f ? (cx - bx) / ex : 0.0f, fy = ey > 0.0f ? (cy - by) / ey : 0.0f, fz = ez > 0.0f ? (cz - bz) / ez : 0.0f;
-    // 21 bits per axis: with 10 the small triangles of a detailed object inside a large scene share
-    // one cell and the bottom of the tree degenerates into index-order splits
-    fx = __builtin_fminf(__builtin_fmaxf(fx * 2097152.0f, 0.0f), 2097151.0f); // NaN -> 0
-    fy = __builtin_fminf(__builtin_fmaxf(fy * 2097152.0f, 0.0f), 2097151.0f);
-    fz = __builtin_fminf(__builtin_fmaxf(fz * 2097152.0f, 0.0f), 2097151.0f);
-    keys[g] = (expand_bits21((uint32_t)fx) << 2) | (expand_bits21((uint32_t)fy) << 1) | expand_bits21((uint32_t)fz);
+    // 30 bits per axis (with 10 the small triangles of a detailed object in a large scene share one
+    // cell and the bottom of the tree degenerates into index-order splits)
+    const float kCells = 1073741824.0f;
+    uint32_t q[3];
+    q[0] = (uint32_t)__builtin_fminf(__builtin_fmaxf(fx * kCells, 0.0f), kCells - 64.0f); // NaN -> 0
+    q[1] = (uint32_t)__builtin_fminf(__builtin_fmaxf(fy * kCells, 0.0f), kCells - 64.0f);
+    q[2] = (uint32_t)__builtin_fminf(__builtin_fmaxf(fz * kCells, 0.0f), kCells - 64.0f);
+    int used[3] = { 0, 0, 0 };
+    unsigned long long key = 0;
+#pragma unroll 1
+    for (int b = 0; b < 63; b++) {
+        const int ax = (int)(((b < 32 ? plan.lo >> (2 * b) : plan.hi >> (2 * (b - 32)))) & 3ull);
+        const uint32_t qa = ax == 0 ? q[0] : (ax == 1 ? q[1] : q[2]);
+        const int u = ax == 0 ? used[0] : (ax == 1 ? used[1] : used[2]);
+        key = (key << 1) | ((qa >> (29 - u)) & 1u);
+        used[0] += ax == 0; used[1] += ax == 1; used[2] += ax == 2;
+    }
+    keys[g] = key;
     vals[g] = g;
 }
 
@@ -494,7 +504,30 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
     }
     out.sceneMaxAbs = maxAbs;
 
-    hipLaunchKernelGGL(morton_kernel, dim3(grid), dim3(256), 0, stream, out.triRef, nTris, dBounds, keysA, valsA);
+    MortonPlan plan{ 0, 0 };
+    {
+        // x, y, z in turn as in a plain Morton code, except that an axis whose cell is already thinner than
+        // RT_MORTON_THIN times the longest cell sits its turn out (always-longest-first measured better on the
+        // flat terrains and worse on the compact model of C2)
+        float ext[3] = { o2f(hbOut[3]) - o2f(hbOut[0]), o2f(hbOut[4]) - o2f(hbOut[1]), o2f(hbOut[5]) - o2f(hbOut[2]) };
+        int used[3] = { 0, 0, 0 };
+        for (int k = 0; k < 3; k++) if (!(ext[k] > 0.0f) || !(ext[k] < FLT_MAX)) ext[k] = 0.0f;
+        int turn = 0;
+        for (int b = 0; b < 63; b++) {
+            float longest = 0.0f;
+            for (int k = 0; k < 3; k++) if (used[k] < 30 && ext[k] > longest) longest = ext[k];
+            int ax = -1;
+            for (int t = 0; t < 3 && ax < 0; t++) {
+                const int k = (turn + t) % 3;
+                if (used[k] < 30 && ext[k] >= RT_MORTON_THIN * longest) ax = k;
+            }
+            if (ax < 0) for (int k = 0; k < 3 && ax < 0; k++) if (used[k] < 30) ax = k;
+            turn = (ax + 1) % 3;
+            used[ax]++; ext[ax] *= 0.5f;
+            if (b < 32) plan.lo |= (unsigned long long)ax << (2 * b); else plan.hi |= (unsigned long long)ax << (2 * (b - 32));
+        }
+    }
+    hipLaunchKernelGGL(morton_kernel, dim3(grid), dim3(256), 0, stream, out.triRef, nTris, dBounds, plan, keysA, valsA);
     RT_HIPC(hipGetLastError());
 
     RT_HIPC(rocprim::radix_sort_pairs(sortTmp, tmpBytes, keysA, keysB, valsA, valsB, (size_t)nTris, 0, 63, stream));
