@@ -16,11 +16,13 @@ that they can be exercised on CPU with gloo:
 """
 from typing import List, Tuple
 
-BAND_ROWS = 16  # multiple of every workgroup tile height (8 or 16 rows)
+BAND_ROWS = 64  # multiple of the 8-row tiles; a band of a 1080p x 16 spp frame is 2 M samples, enough for one wavefront chunk
 
 
 def band_rects(width: int, height: int, rank: int, world: int, band_rows: int = BAND_ROWS) -> List[Tuple[int, int, int, int]]:
     """Row bands [y0, y1) owned by `rank`: band b belongs to rank b % world."""
+    if world == 1:
+        return [(0, 0, width, height)]
     rects = []
     nb = (height + band_rows - 1) // band_rows
     for b in range(rank, nb, world):

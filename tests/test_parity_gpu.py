@@ -458,3 +458,23 @@ def test_wavefront_chunks_and_lanes(ctx, lanes, chunk):
     finally:
         ctx.set_option(capi.OPT_WF_LANES, 0)
         ctx.set_option(capi.OPT_WF_CHUNK, 0)
+
+
+def test_thousands_of_coincident_triangles(ctx):
+    """6 000 copies of one triangle: every box of that subtree is hit by every ray that hits the triangle, all
+    hits tie exactly, and the lowest triangle index has to win (8a-Q3) -- through the four-wide BVH with its
+    quantised boxes and sorted child order just as in the reference's linear scan."""
+    n = 6000
+    tri = np.array([[-1.0, -1.0, 0.0], [1.0, -1.0, 0.0], [0.0, 1.2, 0.3]], np.float32)
+    verts = np.tile(tri, (n, 1))
+    idx = np.arange(3 * n, dtype=np.int32)
+    pile = Mesh(verts.reshape(-1), idx, None, None)
+    sc = Scene()
+    sc.addToScene("pile", MeshObject([(pile, 0)], [Material("m", (0.7, 0.5, 0.3, 1.0), 0.6, 0.1)]))
+    s = Sphere(position=(1.6, 0.2, -0.5)); s.setMaterial(Material("s", (0.3, 0.6, 0.8, 1.0), 0.3, 0.5))
+    sc.addToScene("ball", s)
+    cam = Camera((0.2, 0.1, 5.0)); cam.setWidth(96); cam.setHeight(72); cam.calcRays()
+    st = RenderSettings(bounceCount=3, sampleCount=2)
+    _, rid, _ = compare_modes(ctx, sc.flatten(), cam, st, modes=(0, 2))
+    hit = rid[..., 0] == 0
+    assert hit.any() and (rid[..., 2][hit] == 0).all()
