@@ -127,7 +127,7 @@ void free_wf(rt_ctx* c)
 {
     rt::WfBufs& w = c->wf.bufs[0];
     hipFree(w.rayO); hipFree(w.rayD); hipFree(w.hitA); hipFree(w.hitG); hipFree(w.accO); hipFree(w.accB);
-    hipFree(w.out); hipFree(w.outRays); hipFree(w.pixFlag); hipFree(w.queue); hipFree(w.ctrl);
+    hipFree(w.out); hipFree(w.outRays); hipFree(w.pixFlag); hipFree(w.queue); hipFree(w.exactList); hipFree(w.ctrl);
     for (int j = 0; j < rt::kWfMaxLanes; j++) c->wf.bufs[j] = rt::WfBufs{};
     c->wfCapSlots = 0; c->wfLevels = 0; c->wfLanes = 0;
 }
@@ -146,7 +146,7 @@ hipError_t ensure_wf(rt_ctx* c, size_t slots, int levels, int lanes)
     const size_t pieces = (slots + 255) / 256;
     w.subCap = (uint32_t)(((pieces + rt::kWfStripes - 1) / rt::kWfStripes) * 256);
     const size_t queueWords = 2 * (size_t)rt::kWfStripes * w.subCap;
-    const size_t ctrlWords = (size_t)(levels + 1) * 2 * rt::kWfStripes * rt::kWfCtrlStride + rt::kWfCtrlStride;
+    const size_t ctrlWords = rt::wf_ctrl_words(levels);
     const size_t all = slots * (size_t)lanes;
     const size_t allQ = queueWords * (size_t)lanes; // positions of both ping-pong halves, all lanes
     if (e == hipSuccess) e = hipMalloc((void**)&w.rayO, 16 * allQ);
@@ -159,13 +159,14 @@ hipError_t ensure_wf(rt_ctx* c, size_t slots, int levels, int lanes)
     if (e == hipSuccess) e = hipMalloc((void**)&w.outRays, all);
     if (e == hipSuccess) e = hipMalloc((void**)&w.pixFlag, 4 * all);
     if (e == hipSuccess) e = hipMalloc((void**)&w.queue, sizeof(uint32_t) * queueWords * (size_t)lanes);
+    if (e == hipSuccess) e = hipMalloc((void**)&w.exactList, sizeof(uint32_t) * (allQ / 2));
     if (e == hipSuccess) e = hipMalloc((void**)&w.ctrl, sizeof(uint32_t) * ctrlWords * (size_t)lanes);
     c->wf.bufs[0] = w;
     if (e != hipSuccess) { free_wf(c); return e; }
     for (int j = 1; j < lanes; j++) {
         rt::WfBufs v = w;
         v.rayO += queueWords * j; v.rayD += queueWords * j; v.accO += queueWords * j; v.accB += queueWords * j;
-        v.hitA += (queueWords / 2) * j; v.hitG += (queueWords / 2) * j;
+        v.hitA += (queueWords / 2) * j; v.hitG += (queueWords / 2) * j; v.exactList += (queueWords / 2) * j;
         v.out += slots * j; v.outRays += slots * j; v.pixFlag += slots * j; v.queue += queueWords * j; v.ctrl += ctrlWords * j;
         c->wf.bufs[j] = v;
     }

@@ -128,13 +128,22 @@ struct WfBufs {
     uint8_t* outRays;    // [slot] closest-hit queries of the finished sample
     uint32_t* pixFlag;   // [pixelInChunk] != 0: flagged for the redo launch
     uint32_t* queue;     // [2][kWfStripes][subCap] slots, ping-pong over levels
-    uint32_t* ctrl;      // [level][2][kWfStripes][kWfCtrlStride]: counts, cursors
+    uint32_t* exactList; // [kWfStripes * subCap] hit positions of the rays of the current level that need the exact emulation
+    uint32_t* ctrl;      // [level][2][kWfStripes][kWfCtrlStride]: counts, cursors; then the redo count; then one exact count per level
     uint32_t subCap;
     uint32_t nSlots;
     uint32_t nPix;       // pixels of the chunk = tiles * 64 (edge tiles include pixels outside the rectangle)
     uint32_t tileBegin;  // the chunk's tiles are tileBegin + i * tileStride (tile index over the render rectangle,
     uint32_t tileStride; // row-major): chunks interleave, so that each gets the same mix of cheap and costly tiles
 };
+
+// words of WfBufs::ctrl for `levels` bounce levels, and where the two kinds of single counters sit in it
+__host__ __device__ inline size_t wf_ctrl_words(int levels)
+{
+    return (size_t)(levels + 1) * 2 * kWfStripes * kWfCtrlStride + (size_t)(1 + levels) * kWfCtrlStride;
+}
+__host__ __device__ inline size_t wf_ctrl_redo(int levels) { return (size_t)(levels + 1) * 2 * kWfStripes * kWfCtrlStride; }
+__host__ __device__ inline size_t wf_ctrl_exact(int levels, int level) { return wf_ctrl_redo(levels) + (size_t)(1 + level) * kWfCtrlStride; }
 
 struct RenderArgs {
     SceneView scene;

@@ -823,7 +823,7 @@ __global__ __launch_bounds__(256) void wf_gen_kernel(const RenderArgs a, const W
 #endif
 // closest-hit queries of one level: persistent waves, each lane refilled from the queue as soon as
 // the wave's share of finished lanes makes it worth leaving the traversal loops
-__global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderArgs a, const WfBufs w, const int level)
+__global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderArgs a, const WfBufs w, const int level, const int levels)
 {
     __shared__ uint32_t ldsStack[kWfStack * kBlock];
     __shared__ uint32_t poolSlot[kBlock];
@@ -901,12 +901,15 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
 #endif
         // ---- results of the lanes that finished
         if (have && !trav_running(T)) {
-            bool danger = false;
-            const Hit h = trav_result(T, ray, danger);
-            if (stack.dropped) { danger = true; stack.dropped = false; }
-            if (danger) st.slow++;
+            // a hit of another object inside the tie band: the ray is listed for wf_exact, which replaces this
+            // record before the level is shaded; a dropped stack entry flags the pixel for the redo launch
+            bool band = false;
+            const Hit h = trav_result(T, ray, band);
+            const bool over = stack.dropped;
+            stack.dropped = false;
+            if (band) { st.slow++; w.exactList[atomicAdd(w.ctrl + wf_ctrl_exact(levels, level), 1u)] = hitPos; }
             w.hitA[hitPos] = make_float4(h.t, h.b0, h.b1, h.b2);
-            w.hitG[hitPos] = (h.gid == kNoHit ? kWfMiss : h.gid) | (danger ? kWfDanger : 0u);
+            w.hitG[hitPos] = (h.gid == kNoHit ? kWfMiss : h.gid) | (over ? kWfDanger : 0u);
             have = false;
         }
 #ifdef RT_PHASE_TIMERS
@@ -960,6 +963,31 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
         }
 #endif
     }
+    flush_stats(a, st, wgCnt);
+}
+
+// The rays of a level whose closest hit depends on the reference's object order (another object's hit
+// inside the tie band): traced again with the exact in-order emulation inline, one
+// lane per ray, between the level's trace and shade launches.  Exits at once when the list is empty.
+__global__ __launch_bounds__(256) void wf_exact_kernel(const RenderArgs a, const WfBufs w, const int level, const int levels)
+{
+    __shared__ uint32_t ldsStack[kLdsStack * kBlock];
+    __shared__ uint32_t wgCnt[8];
+    uint32_t ovf[kStackDepth - kLdsStack];
+    Stack stack; stack.lds = ldsStack + threadIdx.x; stack.ovf = ovf;
+    LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
+    const uint32_t n = w.ctrl[wf_ctrl_exact(levels, level)];
+    const size_t half = (size_t)(level & 1) * kWfStripes * (size_t)w.subCap;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t hp = w.exactList[i];
+        const float4 o = w.rayO[half + hp], d = w.rayD[half + hp];
+        Ray ray; ray.ox = o.x; ray.oy = o.y; ray.oz = o.z; ray.maxDist = o.w; ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
+        bool unused = false;
+        const Hit h = closest_hit<3>(a.scene, ray, stack, st, unused);
+        w.hitA[hp] = make_float4(h.t, h.b0, h.b1, h.b2);
+        w.hitG[hp] = (h.gid == kNoHit ? kWfMiss : h.gid) | (w.hitG[hp] & kWfDanger);
+    }
+    st.rays = 0; st.slow = 0; // queries are counted per finished sample, tie-band rays by wf_trace
     flush_stats(a, st, wgCnt);
 }
 
@@ -1164,7 +1192,7 @@ void launch_render_wf(const RenderArgs& a, const WfLanes& L, int numCUs, hipStre
     const uint32_t tilesPerChunk = L.tilesPerChunk;
     if (tilesPerChunk == 0 || L.n <= 0) return;
     const int levels = a.bounceCount > 0 ? a.bounceCount : 0;
-    const size_t ctrlWords = (size_t)(levels + 1) * 2 * kWfStripes * kWfCtrlStride + kWfCtrlStride;
+    const size_t ctrlWords = wf_ctrl_words(levels);
     const uint32_t nChunks = (nTiles + tilesPerChunk - 1) / tilesPerChunk;
     const int used = (int)(nChunks < (uint32_t)L.n ? nChunks : (uint32_t)L.n);
     if (used > 1) {
@@ -1179,7 +1207,7 @@ void launch_render_wf(const RenderArgs& a, const WfLanes& L, int numCUs, hipStre
         w.tileBegin = k; w.tileStride = nChunks; w.nPix = nt * 64u; w.nSlots = w.nPix * spp;
         const uint32_t nPieces = (w.nSlots + 255u) / 256u;
         RenderArgs c = b;
-        c.redoCount = w.ctrl + (ctrlWords - kWfCtrlStride);
+        c.redoCount = w.ctrl + wf_ctrl_redo(levels);
         c.redoList = b.redoList + (size_t)k * tilesPerChunk * 64u;
         hipMemsetAsync(w.ctrl, 0, sizeof(uint32_t) * ctrlWords, stream);
         hipLaunchKernelGGL(wf_gen_kernel, dim3(nPieces), dim3(256), 0, stream, c, w);
@@ -1189,7 +1217,8 @@ void launch_render_wf(const RenderArgs& a, const WfLanes& L, int numCUs, hipStre
         uint32_t gridS = (uint32_t)numCUs * 8u;
         if (gridS > nPieces) gridS = nPieces;
         for (int level = 0; level < levels; level++) {
-            hipLaunchKernelGGL(wf_trace_kernel, dim3(gridT), dim3(256), 0, stream, c, w, level);
+            hipLaunchKernelGGL(wf_trace_kernel, dim3(gridT), dim3(256), 0, stream, c, w, level, levels);
+            hipLaunchKernelGGL(wf_exact_kernel, dim3(gridT < 128u ? gridT : 128u), dim3(256), 0, stream, c, w, level, levels);
             hipLaunchKernelGGL(wf_shade_kernel, dim3(gridS), dim3(256), 0, stream, c, w, level);
         }
         hipLaunchKernelGGL((wf_resolve_kernel<0>), dim3((w.nPix + 255u) / 256u), dim3(256), 0, stream, c, w);
