@@ -966,6 +966,135 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
     flush_stats(a, st, wgCnt);
 }
 
+// Closest-hit queries of level 0 as packets: the 64 camera rays of a block (neighbouring pixels, all their
+// samples) walk the tree together.  Node, stack and child order are wave-uniform -- the node arrives
+// through scalar loads instead of 64 divergent fetches, the stack is one VGPR indexed by lane
+// (v_writelane / v_readlane), there is no per-lane scheduling -- while every lane tests the boxes and
+// triangles against its own ray and keeps its own closest hit, so the result per ray is what wf_trace
+// gives: a node is entered when any lane's ray enters it, and a lane that does not merely tests
+// triangles its ray cannot hit.  Only worth it for coherent rays: after the first bounce the union of
+// 64 rays' nodes is most of the tree.
+__global__ __launch_bounds__(256) void wf_trace_packet_kernel(const RenderArgs a, const WfBufs w, const int level, const int levels)
+{
+    __shared__ uint32_t wgCnt[8];
+    const int lane = threadIdx.x & 63;
+    LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
+    const uint32_t waveId = blockIdx.x * 4u + (threadIdx.x >> 6);
+    uint32_t stripe = waveId % kWfStripes, stripeCnt = 0;
+    unsigned long long exhausted = 0ull;
+    bool stripeOk = false, pendIssued = false;
+    uint32_t pendC = 0;
+    auto pick_stripe = [&]() -> bool {
+        if (stripeOk && !(exhausted & (1ull << stripe))) return true;
+        for (int k = 0; k < kWfStripes; k++) {
+            const uint32_t sidx = (stripe + (uint32_t)k) % kWfStripes;
+            if (exhausted & (1ull << sidx)) continue;
+            const uint32_t cnt = *wf_count(w, level, (int)sidx);
+            if (cnt == 0u) { exhausted |= 1ull << sidx; continue; }
+            stripe = sidx; stripeCnt = cnt; stripeOk = true;
+            return true;
+        }
+        stripeOk = false;
+        return false;
+    };
+    auto issue_claim = [&]() {
+        pendIssued = pick_stripe();
+        if (pendIssued && lane == 0) pendC = atomicAdd(wf_cursor(w, level, (int)stripe), 64u);
+    };
+    issue_claim();
+    for (;;) {
+        // ---- the block claimed last time round; the next claim's atomic goes out before the walk
+        uint32_t off = 0, n = 0, blockStripe = 0;
+        bool got = false;
+        while (pendIssued) {
+            const uint32_t c = (uint32_t)__shfl((int)pendC, 0);
+            if (c < stripeCnt) { off = c; n = stripeCnt - c < 64u ? stripeCnt - c : 64u; blockStripe = stripe; got = true; break; }
+            exhausted |= 1ull << stripe;
+            issue_claim();
+        }
+        if (!got) break;
+        issue_claim();
+        const size_t p = wf_pos(w, level, blockStripe, off + (uint32_t)lane);
+        const uint32_t slot = (uint32_t)lane < n ? w.queue[p] : kWfHole;
+        const bool active = slot != kWfHole;
+        Ray ray; ray.ox = ray.oy = ray.oz = 0.0f; ray.dx = 1.0f; ray.dy = ray.dz = 0.0f; ray.maxDist = -1.0f;
+        if (active) {
+            const float4 o = w.rayO[p], d = w.rayD[p];
+            ray.ox = o.x; ray.oy = o.y; ray.oz = o.z; ray.maxDist = o.w; ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
+        }
+        Trav T; trav_init(T, a.scene, ray); // a lane without a ray has bound -1: it enters no box and accepts no hit
+        if (__ballot(active) == 0ull) continue;
+        bool overflow = false;
+        if (a.scene.rootIsValid) {
+            uint32_t stk = 0;      // the wave's stack: entry i lives in lane i
+            int sp = 0;            // wave-uniform
+            int32_t node = 0;      // wave-uniform
+            for (;;) {
+                if (node >= 0) {
+                    const float4* np = reinterpret_cast<const float4*>(a.scene.nodes + node);
+                    const float4 N0 = np[0];
+                    const uint4 N1 = reinterpret_cast<const uint4*>(np)[1], N2 = reinterpret_cast<const uint4*>(np)[2];
+                    const int4 CH = reinterpret_cast<const int4*>(np)[3];
+                    uint32_t k[4];
+                    node_test(T.br, N0, N1, N2, T.bound, k);
+                    st.bvh.nodes += active ? 1u : 0u;
+                    // children some lane enters, ordered by the entry distances of the first lane that enters any
+                    const unsigned long long h0 = __ballot(k[0] != kMissKey), h1 = __ballot(k[1] != kMissKey),
+                                             h2 = __ballot(k[2] != kMissKey), h3 = __ballot(k[3] != kMissKey);
+                    const unsigned long long any = h0 | h1 | h2 | h3;
+                    int h = 0;
+                    if (any != 0ull) {
+                        const int rep = __builtin_ctzll(any);
+                        uint32_t ks[4]; int32_t cs[4] = { CH.x, CH.y, CH.z, CH.w };
+                        const unsigned long long hm[4] = { h0, h1, h2, h3 };
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            const uint32_t kr = (uint32_t)__builtin_amdgcn_readlane((int)k[c], rep);
+                            ks[c] = hm[c] == 0ull ? kMissKey : (kr == kMissKey ? 0xFFFFFFFEu : kr);
+                            h += hm[c] != 0ull;
+                            cs[c] = __builtin_amdgcn_readfirstlane(cs[c]);
+                        }
+                        cmp_swap(ks[0], ks[1], cs[0], cs[1]); cmp_swap(ks[2], ks[3], cs[2], cs[3]);
+                        cmp_swap(ks[0], ks[2], cs[0], cs[2]); cmp_swap(ks[1], ks[3], cs[1], cs[3]);
+                        cmp_swap(ks[1], ks[2], cs[1], cs[2]);
+                        if (sp + 3 > 64) overflow = true;
+                        else {
+                            if (h >= 4) { stk = lane == sp ? (uint32_t)cs[3] : stk; sp++; }
+                            if (h >= 3) { stk = lane == sp ? (uint32_t)cs[2] : stk; sp++; }
+                            if (h >= 2) { stk = lane == sp ? (uint32_t)cs[1] : stk; sp++; }
+                        }
+                        node = cs[0];
+                    }
+                    if (h == 0) {
+                        if (sp == 0) break;
+                        node = __builtin_amdgcn_readlane((int)stk, --sp);
+                    }
+                } else {
+                    const uint32_t code = (uint32_t)(~node);
+                    const uint32_t first = code >> 3, count = code & 7u;
+                    for (uint32_t q = 0; q < count; q++) {
+                        const float4* tp = reinterpret_cast<const float4*>(a.scene.triLeaf + T.triBase + first + q);
+                        const float4 A = tp[0], B = tp[1], C = tp[2];
+                        st.bvh.tris += active ? 1u : 0u;
+                        trav_test_triangle(T, A, B, C);
+                    }
+                    if (sp == 0) break;
+                    node = __builtin_amdgcn_readlane((int)stk, --sp);
+                }
+            }
+        }
+        if (active) {
+            bool band = false;
+            const Hit hres = trav_result(T, ray, band);
+            const uint32_t hitPos = (uint32_t)wf_hit_pos(w, blockStripe, off + (uint32_t)lane);
+            if (band) { st.slow++; w.exactList[atomicAdd(w.ctrl + wf_ctrl_exact(levels, level), 1u)] = hitPos; }
+            w.hitA[hitPos] = make_float4(hres.t, hres.b0, hres.b1, hres.b2);
+            w.hitG[hitPos] = (hres.gid == kNoHit ? kWfMiss : hres.gid) | (overflow ? kWfDanger : 0u);
+        }
+    }
+    flush_stats(a, st, wgCnt);
+}
+
 // The rays of a level whose closest hit depends on the reference's object order (another object's hit
 // inside the tie band): traced again with the exact in-order emulation inline, one
 // lane per ray, between the level's trace and shade launches.  Exits at once when the list is empty.
@@ -1217,7 +1346,8 @@ void launch_render_wf(const RenderArgs& a, const WfLanes& L, int numCUs, hipStre
         uint32_t gridS = (uint32_t)numCUs * 8u;
         if (gridS > nPieces) gridS = nPieces;
         for (int level = 0; level < levels; level++) {
-            hipLaunchKernelGGL(wf_trace_kernel, dim3(gridT), dim3(256), 0, stream, c, w, level, levels);
+            if (level == 0) hipLaunchKernelGGL(wf_trace_packet_kernel, dim3(gridT), dim3(256), 0, stream, c, w, level, levels);
+            else hipLaunchKernelGGL(wf_trace_kernel, dim3(gridT), dim3(256), 0, stream, c, w, level, levels);
             hipLaunchKernelGGL(wf_exact_kernel, dim3(gridT < 128u ? gridT : 128u), dim3(256), 0, stream, c, w, level, levels);
             hipLaunchKernelGGL(wf_shade_kernel, dim3(gridS), dim3(256), 0, stream, c, w, level);
         }

@@ -560,8 +560,8 @@ struct Trav {
     TriRay q;
     BoxRay br;
 };
-template <class HS>
-__device__ __forceinline__ void trav_begin(Trav& T, const SceneView& s, const Ray& ray, HS& stack)
+// per-ray part of the state (everything but the lane's position in the tree)
+__device__ __forceinline__ void trav_init(Trav& T, const SceneView& s, const Ray& ray)
 {
     T.q = make_tri_ray(ray);
     T.br = make_box_ray(ray, s.sceneMaxAbs);
@@ -571,7 +571,15 @@ __device__ __forceinline__ void trav_begin(Trav& T, const SceneView& s, const Ra
     T.best.t = FLT_MAX; T.best.gid = kNoHit; T.best.b0 = T.best.b1 = T.best.b2 = 0.0f;
     T.bestObj = kNoHit; T.otherT = FLT_MAX;
     T.cc.obj = kNoHit; T.cc.tmin = 0.0f; T.cc.bfar = 0.0f;
-    stack.reset(T.sp); T.triFirst = 0; T.triCount = 0; T.triBase = (uint32_t)T.q.kz * s.nTris;
+    T.triFirst = 0; T.triCount = 0; T.triBase = (uint32_t)T.q.kz * s.nTris;
+    T.sp = 0; T.node = kTravEnd;
+}
+
+template <class HS>
+__device__ __forceinline__ void trav_begin(Trav& T, const SceneView& s, const Ray& ray, HS& stack)
+{
+    trav_init(T, s, ray);
+    stack.reset(T.sp);
     T.node = s.rootIsValid ? 0 : kTravEnd;
 }
 
@@ -588,6 +596,28 @@ __device__ __forceinline__ void trav_take_leaf(Trav& T, const SceneView& s, HS& 
     }
 }
 
+// One triangle of a reached leaf against the lane's ray: the reference's test on the rotated record,
+// then the bookkeeping of the winner and of the closest hit on any other object.
+// The object-space cull of the winner's object (GPURaytracer.cu:267-315) is checked once, by the
+// shading side: a hit on an object whose cull fails (flat meshes) sends the pixel to the
+// redo launch instead of costing every triangle step a 96-byte fetch and a slab test.
+__device__ __forceinline__ void trav_test_triangle(Trav& T, const float4& A, const float4& B, const float4& C)
+{
+    float t, b0, b1, b2;
+    if (tri_test_rot(T.q, T.m0, A, B, C, t, b0, b1, b2) && t <= T.bound) {
+        const uint32_t gid = __float_as_uint(A.w), obj = __float_as_uint(B.w);
+        const bool better = t < T.best.t || (t == T.best.t && gid < T.best.gid);
+        if (obj != T.bestObj) {
+            if (better) { if (T.best.gid != kNoHit) T.otherT = T.best.t; T.bestObj = obj; }
+            else T.otherT = __builtin_fminf(T.otherT, t);
+        }
+        if (better) {
+            T.best.t = t; T.best.b0 = b0; T.best.b1 = b1; T.best.b2 = b2; T.best.gid = gid;
+            T.bound = __builtin_fminf(T.m0, t + band_of(t, T.rayScale));
+        }
+    }
+}
+
 template <class HS>
 __device__ __forceinline__ void trav_tri_step(Trav& T, const SceneView& s, const Ray& ray, HS& stack, BvhCounters& cnt)
 {
@@ -596,22 +626,7 @@ __device__ __forceinline__ void trav_tri_step(Trav& T, const SceneView& s, const
         const float4 A = p[0], B = p[1], C = p[2];
         T.triFirst++; T.triCount--;
         cnt.tris++;
-        float t, b0, b1, b2;
-        // The object-space cull of the winner's object (GPURaytracer.cu:267-315) is checked once, in
-        // trav_finish: a hit on an object whose cull fails (flat meshes) sends the pixel to
-        // the redo launch instead of costing every triangle step a 96-byte fetch and a slab test.
-        if (tri_test_rot(T.q, T.m0, A, B, C, t, b0, b1, b2) && t <= T.bound) {
-            const uint32_t gid = __float_as_uint(A.w), obj = __float_as_uint(B.w);
-            const bool better = t < T.best.t || (t == T.best.t && gid < T.best.gid);
-            if (obj != T.bestObj) {
-                if (better) { if (T.best.gid != kNoHit) T.otherT = T.best.t; T.bestObj = obj; }
-                else T.otherT = __builtin_fminf(T.otherT, t);
-            }
-            if (better) {
-                T.best.t = t; T.best.b0 = b0; T.best.b1 = b1; T.best.b2 = b2; T.best.gid = gid;
-                T.bound = __builtin_fminf(T.m0, t + band_of(t, T.rayScale));
-            }
-        }
+        trav_test_triangle(T, A, B, C);
     }
     trav_take_leaf(T, s, stack);
 }
