@@ -41,7 +41,9 @@ def build_workload(name, args):
         fn = getattr(scenes, "config" + name[1:], None)
         if fn is None:
             raise SystemExit(f"unknown workload {name}")
-        scene, cam, st = fn(args.width, args.height, args.spp, args.depth) if (args.width or args.spp) else fn()
+        names = fn.__code__.co_varnames[:fn.__code__.co_argcount]
+        given = {"width": args.width, "height": args.height, "spp": args.spp, "depth": args.depth}
+        scene, cam, st = fn(**{k: v for k, v in given.items() if v and k in names})
         label = fn.__doc__.strip().split("\n")[0]
     return scene, cam, st, label
 

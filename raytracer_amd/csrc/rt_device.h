@@ -128,8 +128,8 @@ struct WfBufs {
     uint8_t* outRays;    // [slot] closest-hit queries of the finished sample
     uint32_t* pixFlag;   // [pixelInChunk] != 0: flagged for the redo launch
     uint32_t* queue;     // [2][kWfStripes][subCap] slots, ping-pong over levels
-    uint32_t* exactList; // [kWfStripes * subCap] hit positions of the rays of the current level that need the exact emulation
-    uint32_t* ctrl;      // [level][2][kWfStripes][kWfCtrlStride]: counts, cursors; then the redo count; then one exact count per level
+    uint32_t* exactList; // [kWfStripes][subCap] hit positions of the rays of the current level that need the exact emulation, listed per stripe
+    uint32_t* ctrl;      // [level][2][kWfStripes][kWfCtrlStride]: counts, cursors; then the redo count; then per level one exact count per stripe (one same-address atomic stream per stripe: a single counter capped the trace kernels at its ~90 appends per microsecond)
     uint32_t subCap;
     uint32_t nSlots;
     uint32_t nPix;       // pixels of the chunk = tiles * 64 (edge tiles include pixels outside the rectangle)
@@ -140,10 +140,13 @@ struct WfBufs {
 // words of WfBufs::ctrl for `levels` bounce levels, and where the two kinds of single counters sit in it
 __host__ __device__ inline size_t wf_ctrl_words(int levels)
 {
-    return (size_t)(levels + 1) * 2 * kWfStripes * kWfCtrlStride + (size_t)(1 + levels) * kWfCtrlStride;
+    return (size_t)(levels + 1) * 2 * kWfStripes * kWfCtrlStride + (size_t)(1 + levels * kWfStripes) * kWfCtrlStride;
 }
 __host__ __device__ inline size_t wf_ctrl_redo(int levels) { return (size_t)(levels + 1) * 2 * kWfStripes * kWfCtrlStride; }
-__host__ __device__ inline size_t wf_ctrl_exact(int levels, int level) { return wf_ctrl_redo(levels) + (size_t)(1 + level) * kWfCtrlStride; }
+__host__ __device__ inline size_t wf_ctrl_exact(int levels, int level, int stripe)
+{
+    return wf_ctrl_redo(levels) + (size_t)(1 + level * kWfStripes + stripe) * kWfCtrlStride;
+}
 
 struct RenderArgs {
     SceneView scene;

@@ -907,7 +907,11 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
             const Hit h = trav_result(T, ray, band);
             const bool over = stack.dropped;
             stack.dropped = false;
-            if (band) { st.slow++; w.exactList[atomicAdd(w.ctrl + wf_ctrl_exact(levels, level), 1u)] = hitPos; }
+            if (band) { // listed under the stripe the ray sits in: that list cannot overflow
+                st.slow++;
+                const uint32_t bs = hitPos / w.subCap;
+                w.exactList[(size_t)bs * w.subCap + atomicAdd(w.ctrl + wf_ctrl_exact(levels, level, (int)bs), 1u)] = hitPos;
+            }
             w.hitA[hitPos] = make_float4(h.t, h.b0, h.b1, h.b2);
             w.hitG[hitPos] = (h.gid == kNoHit ? kWfMiss : h.gid) | (over ? kWfDanger : 0u);
             have = false;
@@ -974,7 +978,10 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
 // gives: a node is entered when any lane's ray enters it, and a lane that does not merely tests
 // triangles its ray cannot hit.  Only worth it for coherent rays: after the first bounce the union of
 // 64 rays' nodes is most of the tree.
-__global__ __launch_bounds__(256) void wf_trace_packet_kernel(const RenderArgs a, const WfBufs w, const int level, const int levels)
+#ifndef RT_PK_OCC
+#define RT_PK_OCC 6
+#endif
+__global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const RenderArgs a, const WfBufs w, const int level, const int levels)
 {
     __shared__ uint32_t wgCnt[8];
     const int lane = threadIdx.x & 63;
@@ -1013,6 +1020,9 @@ __global__ __launch_bounds__(256) void wf_trace_packet_kernel(const RenderArgs a
             issue_claim();
         }
         if (!got) break;
+#ifdef RT_PHASE_TIMERS
+        const long long tk0 = clock64();
+#endif
         issue_claim();
         const size_t p = wf_pos(w, level, blockStripe, off + (uint32_t)lane);
         const uint32_t slot = (uint32_t)lane < n ? w.queue[p] : kWfHole;
@@ -1025,6 +1035,10 @@ __global__ __launch_bounds__(256) void wf_trace_packet_kernel(const RenderArgs a
         Trav T; trav_init(T, a.scene, ray); // a lane without a ray has bound -1: it enters no box and accepts no hit
         if (__ballot(active) == 0ull) continue;
         bool overflow = false;
+#ifdef RT_PHASE_TIMERS
+        const long long tk1 = clock64();
+        int dbgNodes = 0, dbgLeaves = 0, dbgSp = 0;
+#endif
         if (a.scene.rootIsValid) {
             uint32_t stk = 0;      // the wave's stack: entry i lives in lane i
             int sp = 0;            // wave-uniform
@@ -1038,6 +1052,9 @@ __global__ __launch_bounds__(256) void wf_trace_packet_kernel(const RenderArgs a
                     uint32_t k[4];
                     node_test(T.br, N0, N1, N2, T.bound, k);
                     st.bvh.nodes += active ? 1u : 0u;
+#ifdef RT_PHASE_TIMERS
+                    dbgNodes++; dbgSp = sp > dbgSp ? sp : dbgSp;
+#endif
                     // children some lane enters, ordered by the entry distances of the first lane that enters any
                     const unsigned long long h0 = __ballot(k[0] != kMissKey), h1 = __ballot(k[1] != kMissKey),
                                              h2 = __ballot(k[2] != kMissKey), h3 = __ballot(k[3] != kMissKey);
@@ -1072,6 +1089,9 @@ __global__ __launch_bounds__(256) void wf_trace_packet_kernel(const RenderArgs a
                 } else {
                     const uint32_t code = (uint32_t)(~node);
                     const uint32_t first = code >> 3, count = code & 7u;
+#ifdef RT_PHASE_TIMERS
+                    dbgLeaves++;
+#endif
                     for (uint32_t q = 0; q < count; q++) {
                         const float4* tp = reinterpret_cast<const float4*>(a.scene.triLeaf + T.triBase + first + q);
                         const float4 A = tp[0], B = tp[1], C = tp[2];
@@ -1083,14 +1103,31 @@ __global__ __launch_bounds__(256) void wf_trace_packet_kernel(const RenderArgs a
                 }
             }
         }
+#ifdef RT_PHASE_TIMERS
+        const long long tk2 = clock64();
+#endif
         if (active) {
             bool band = false;
             const Hit hres = trav_result(T, ray, band);
             const uint32_t hitPos = (uint32_t)wf_hit_pos(w, blockStripe, off + (uint32_t)lane);
-            if (band) { st.slow++; w.exactList[atomicAdd(w.ctrl + wf_ctrl_exact(levels, level), 1u)] = hitPos; }
+            if (band) {
+                st.slow++;
+                w.exactList[(size_t)blockStripe * w.subCap + atomicAdd(w.ctrl + wf_ctrl_exact(levels, level, (int)blockStripe), 1u)] = hitPos;
+            }
             w.hitA[hitPos] = make_float4(hres.t, hres.b0, hres.b1, hres.b2);
             w.hitG[hitPos] = (hres.gid == kNoHit ? kWfMiss : hres.gid) | (overflow ? kWfDanger : 0u);
         }
+#ifdef RT_PHASE_TIMERS
+        if (lane == 0) { // slots as in wf_trace: burst = the walk, write = results, refill = claim + ray fetch + set-up
+            st.bvh.idleA += (uint32_t)((tk2 - tk1) >> 6); st.bvh.idleB += (uint32_t)((clock64() - tk2) >> 6);
+            st.bvh.diagA += (uint32_t)((tk1 - tk0) >> 6); st.slow++;
+            if (tk2 - tk1 > (1ll << 22)) {
+                int px, py; wf_pixel(a, w, slot / a.sampleCount, px, py);
+                printf("long block: pixel %d %d  cycles %lld  node steps %d leaf steps %d  max sp %d\n", px, py, tk2 - tk1, dbgNodes, dbgLeaves, dbgSp);
+            }
+            if (tk2 - tk1 > (1ll << 20)) st.bvh.diagB += tk2 - tk1 > (1ll << 24) ? (1u << 20) : (tk2 - tk1 > (1ll << 22) ? (1u << 10) : 1u);
+        }
+#endif
     }
     flush_stats(a, st, wgCnt);
 }
@@ -1105,10 +1142,28 @@ __global__ __launch_bounds__(256) void wf_exact_kernel(const RenderArgs a, const
     uint32_t ovf[kStackDepth - kLdsStack];
     Stack stack; stack.lds = ldsStack + threadIdx.x; stack.ovf = ovf;
     LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
-    const uint32_t n = w.ctrl[wf_ctrl_exact(levels, level)];
+    // the stripes' lists read as one: entry i belongs to the last stripe whose running total is <= i
+    __shared__ uint32_t listBase[kWfStripes + 1];
+    if (threadIdx.x < 64) {
+        const uint32_t cnt = w.ctrl[wf_ctrl_exact(levels, level, (int)threadIdx.x)];
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+            if ((int)threadIdx.x >= d) incl += up;
+        }
+        listBase[threadIdx.x + 1] = incl;
+        if (threadIdx.x == 0) listBase[0] = 0u;
+    }
+    __syncthreads();
+    const uint32_t n = listBase[kWfStripes];
     const size_t half = (size_t)(level & 1) * kWfStripes * (size_t)w.subCap;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const uint32_t hp = w.exactList[i];
+        uint32_t ls = 0;
+#pragma unroll
+        for (uint32_t step = kWfStripes / 2; step > 0; step >>= 1)
+            if (listBase[ls + step] <= i) ls += step;
+        const uint32_t hp = w.exactList[(size_t)ls * w.subCap + (i - listBase[ls])];
         const float4 o = w.rayO[half + hp], d = w.rayD[half + hp];
         Ray ray; ray.ox = o.x; ray.oy = o.y; ray.oz = o.z; ray.maxDist = o.w; ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
         bool unused = false;
@@ -1346,7 +1401,11 @@ void launch_render_wf(const RenderArgs& a, const WfLanes& L, int numCUs, hipStre
         uint32_t gridS = (uint32_t)numCUs * 8u;
         if (gridS > nPieces) gridS = nPieces;
         for (int level = 0; level < levels; level++) {
-            if (level == 0) hipLaunchKernelGGL(wf_trace_packet_kernel, dim3(gridT), dim3(256), 0, stream, c, w, level, levels);
+            if (level == 0) {
+                uint32_t gridP = (uint32_t)numCUs * RT_PK_OCC;
+                if (gridP > needT) gridP = needT;
+                hipLaunchKernelGGL(wf_trace_packet_kernel, dim3(gridP), dim3(256), 0, stream, c, w, level, levels);
+            }
             else hipLaunchKernelGGL(wf_trace_kernel, dim3(gridT), dim3(256), 0, stream, c, w, level, levels);
             hipLaunchKernelGGL(wf_exact_kernel, dim3(gridT < 128u ? gridT : 128u), dim3(256), 0, stream, c, w, level, levels);
             hipLaunchKernelGGL(wf_shade_kernel, dim3(gridS), dim3(256), 0, stream, c, w, level);

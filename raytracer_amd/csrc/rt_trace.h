@@ -235,7 +235,17 @@ __device__ __forceinline__ BoxRay make_box_ray(const Ray& r, float sceneMaxAbs)
     // as fma(plane, 1/d, -o/d), whose rounding error is half an ulp of |o| in plane position:
     // far inside the pad.
     const float pad = scale * 3.8146973e-06f + 1e-30f;
-    b.ix = 1.0f / r.dx; b.iy = 1.0f / r.dy; b.iz = 1.0f / r.dz;
+    // A direction component of (nearly) zero is replaced by +-1e-30: the slab distances stay finite
+    // ((plane - o) * 1e30 < FLT_MAX for any scene that fits floats), the ray's true drift along that
+    // axis over any distance of interest is far inside the pad, and a ray that runs inside a slab sees
+    // it as open-ended.  With 1/0 the distances were inf - inf = NaN, the axis dropped out of the test,
+    // and the centre column of an axis-aligned camera visited every box in its plane: single rays with
+    // 10 000 node visits that set the length of the trace launches on C4 and C5.
+    const float kTiny = 1e-30f;
+    const float ddx = __builtin_fabsf(r.dx) < kTiny ? __builtin_copysignf(kTiny, r.dx) : r.dx;
+    const float ddy = __builtin_fabsf(r.dy) < kTiny ? __builtin_copysignf(kTiny, r.dy) : r.dy;
+    const float ddz = __builtin_fabsf(r.dz) < kTiny ? __builtin_copysignf(kTiny, r.dz) : r.dz;
+    b.ix = 1.0f / ddx; b.iy = 1.0f / ddy; b.iz = 1.0f / ddz;
     b.sx = __builtin_signbit(r.dx); b.sy = __builtin_signbit(r.dy); b.sz = __builtin_signbit(r.dz);
     b.cnx = -((b.sx ? r.ox - pad : r.ox + pad) * b.ix);  b.cfx = -((b.sx ? r.ox + pad : r.ox - pad) * b.ix);
     b.cny = -((b.sy ? r.oy - pad : r.oy + pad) * b.iy);  b.cfy = -((b.sy ? r.oy + pad : r.oy - pad) * b.iy);
@@ -248,8 +258,8 @@ __device__ __forceinline__ BoxRay make_box_ray(const Ray& r, float sceneMaxAbs)
 // ensure.  With plane = origin + q * scale, the distance to a plane is
 //   (plane - o) / d = q * (scale / d) + (origin - o) / d = fma(q, a, b)
 // with a, b per node and axis, so a child costs one byte-to-float conversion and one FMA per plane.
-// fmax/fmin drop NaN operands (0 * inf or inf - inf when a direction component is zero): the axis
-// is then ignored, which errs on the side of visiting.
+// fmax/fmin drop NaN operands, which errs on the side of visiting (make_box_ray keeps 1/d finite,
+// so none arise from axis-parallel rays).
 // key[c] = bits of the entry distance (>= 0, so unsigned order = float order) or ~0 for a miss.
 constexpr uint32_t kMissKey = 0xFFFFFFFFu;
 
