@@ -978,6 +978,9 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
 // gives: a node is entered when any lane's ray enters it, and a lane that does not merely tests
 // triangles its ray cannot hit.  Only worth it for coherent rays: after the first bounce the union of
 // 64 rays' nodes is most of the tree.
+#ifndef RT_EXACT_GRID
+#define RT_EXACT_GRID 128u
+#endif
 #ifndef RT_PK_OCC
 #define RT_PK_OCC 6
 #endif
@@ -1166,8 +1169,11 @@ __global__ __launch_bounds__(256) void wf_exact_kernel(const RenderArgs a, const
         const uint32_t hp = w.exactList[(size_t)ls * w.subCap + (i - listBase[ls])];
         const float4 o = w.rayO[half + hp], d = w.rayD[half + hp];
         Ray ray; ray.ox = o.x; ray.oy = o.y; ray.oz = o.z; ray.maxDist = o.w; ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
-        bool unused = false;
-        const Hit h = closest_hit<3>(a.scene, ray, stack, st, unused);
+        Hit h;
+        if (!trace_band_table(a.scene, ray, w.hitA[hp].x, stack, st.bvh, h)) {
+            bool unused = false;
+            h = closest_hit<3>(a.scene, ray, stack, st, unused);
+        }
         w.hitA[hp] = make_float4(h.t, h.b0, h.b1, h.b2);
         w.hitG[hp] = (h.gid == kNoHit ? kWfMiss : h.gid) | (w.hitG[hp] & kWfDanger);
     }
@@ -1407,7 +1413,7 @@ void launch_render_wf(const RenderArgs& a, const WfLanes& L, int numCUs, hipStre
                 hipLaunchKernelGGL(wf_trace_packet_kernel, dim3(gridP), dim3(256), 0, stream, c, w, level, levels);
             }
             else hipLaunchKernelGGL(wf_trace_kernel, dim3(gridT), dim3(256), 0, stream, c, w, level, levels);
-            hipLaunchKernelGGL(wf_exact_kernel, dim3(gridT < 128u ? gridT : 128u), dim3(256), 0, stream, c, w, level, levels);
+            hipLaunchKernelGGL(wf_exact_kernel, dim3(gridT < RT_EXACT_GRID ? gridT : RT_EXACT_GRID), dim3(256), 0, stream, c, w, level, levels);
             hipLaunchKernelGGL(wf_shade_kernel, dim3(gridS), dim3(256), 0, stream, c, w, level);
         }
         hipLaunchKernelGGL((wf_resolve_kernel<0>), dim3((w.nPix + 255u) / 256u), dim3(256), 0, stream, c, w);

@@ -61,9 +61,12 @@ __device__ __forceinline__ TriRay make_tri_ray(const Ray& r)
 // :551-637.  Returns true and fills t / barycentrics when the triangle is hit within
 // (0.001, maxDist]; bit-for-bit the oracle's dist_to_triangle.
 // core of the test on vertices already translated to the ray origin and rotated into (kx, ky, kz)
+// tsOut / detOut: the operands of the reference's pre-filter on maxDist (tScaled against maxDist * det), for
+// callers that must know whether a hit accepted under one maxDist is accepted under a smaller one
 __device__ __forceinline__ bool tri_test_core(const TriRay& q, float maxDist, float p0x, float p0y, float p0z, float p1x,
                                               float p1y, float p1z, float p2x, float p2y, float p2z, float& tOut,
-                                              float& b0Out, float& b1Out, float& b2Out)
+                                              float& b0Out, float& b1Out, float& b2Out, float* tsOut = nullptr,
+                                              float* detOut = nullptr)
 {
     p0x += q.sx * p0z; p0y += q.sy * p0z;
     p1x += q.sx * p1z; p1y += q.sy * p1z;
@@ -97,6 +100,8 @@ __device__ __forceinline__ bool tri_test_core(const TriRay& q, float maxDist, fl
     if (!(t < FLT_MAX)) return false; // reference: a FLT_MAX / NaN distance never wins '<' (:421)
 
     tOut = t; b0Out = e0 * invDet; b1Out = e1 * invDet; b2Out = e2 * invDet;
+    if (tsOut) *tsOut = tScaled;
+    if (detOut) *detOut = det;
     return true;
 }
 
@@ -118,10 +123,11 @@ __device__ __forceinline__ bool tri_test(const Ray& r, const TriRay& q, float ma
 // vertices from the leaf-order copy already rotated for this ray's kz (SceneView::triLeaf): the same
 // subtractions on the same operands as above, without the 18 three-way selects per triangle
 __device__ __forceinline__ bool tri_test_rot(const TriRay& q, float maxDist, const float4& A, const float4& B,
-                                             const float4& C, float& tOut, float& b0Out, float& b1Out, float& b2Out)
+                                             const float4& C, float& tOut, float& b0Out, float& b1Out, float& b2Out,
+                                             float* tsOut = nullptr, float* detOut = nullptr)
 {
     return tri_test_core(q, maxDist, A.x - q.pox, A.y - q.poy, A.z - q.poz, B.x - q.pox, B.y - q.poy, B.z - q.poz,
-                         C.x - q.pox, C.y - q.poy, C.z - q.poz, tOut, b0Out, b1Out, b2Out);
+                         C.x - q.pox, C.y - q.poy, C.z - q.poz, tOut, b0Out, b1Out, b2Out, tsOut, detOut);
 }
 
 // :728-743 (transpose == false), columns c0..c3 of a column-major 16-float matrix
@@ -499,6 +505,76 @@ __device__ __noinline__ Hit trace_bvh_exact(const SceneView& s, Ray& ray, const 
     }
     ray.maxDist = m;
     return best;
+}
+
+// The same emulation in one walk, for a ray already known to sit in the tie band (wf_exact); tBest is the
+// distance of the closest hit that the band-free traversal found, without any object cull.  The walk,
+// bounded by the band limit, keeps per object the closest hit accepted under m0 -- two objects fit: the
+// floor under a bin, a sphere sunk into the terrain -- and the reference's loop over the objects in id
+// order (:247-265) is replayed on that table: an object's closest hit under a smaller maxDistance m is
+// the same triangle as long as that triangle is still accepted (acceptance is monotone in m), and no hit
+// at all when its distance exceeds m.  Returns false, and the caller runs the full emulation above, when
+//   - a third object has a hit inside the limit,
+//   - a hit's object fails its cull under m0 (tBest may then not be the closest accepted hit), or
+//   - a table hit lies within m but the reference's pre-filter (tScaled against m * det) rejects it:
+//     another triangle of that object could then be the one the reference finds.
+struct BandEntry {
+    uint32_t obj;
+    Hit h;
+    float ts, det;
+};
+
+__device__ __forceinline__ bool trace_band_table(const SceneView& s, Ray& ray, float tBest, Stack& stack, BvhCounters& cnt,
+                                                 Hit& out)
+{
+    const TriRay q = make_tri_ray(ray);
+    const BoxRay br = make_box_ray(ray, s.sceneMaxAbs);
+    const float rayScale = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ray.ox), __builtin_fabsf(ray.oy)),
+                                           __builtin_fmaxf(__builtin_fabsf(ray.oz), s.sceneMaxAbs));
+    const float m0 = ray.maxDist;
+    const float limit = __builtin_fminf(tBest + band_of(tBest, rayScale), m0);
+    BandEntry e0, e1;
+    e0.obj = e1.obj = kNoHit;
+    e0.h.t = e1.h.t = FLT_MAX; e0.h.gid = e1.h.gid = kNoHit;
+    e0.h.b0 = e0.h.b1 = e0.h.b2 = e1.h.b0 = e1.h.b1 = e1.h.b2 = 0.0f;
+    e0.ts = e0.det = e1.ts = e1.det = 0.0f;
+    bool ok = true;
+    CullCache cc; cc.obj = kNoHit; cc.tmin = 0.0f; cc.bfar = 0.0f;
+    bvh_walk(s, br, q, limit, stack, cnt, [&](const float4& A, const float4& B, const float4& C, float bound) {
+        float t, b0, b1, b2, ts, det;
+        if (!tri_test_rot(q, m0, A, B, C, t, b0, b1, b2, &ts, &det) || t > limit) return bound;
+        const uint32_t gid = __float_as_uint(A.w), obj = __float_as_uint(B.w);
+        cull_lookup(s, ray, obj, cc);
+        auto keep = [&](BandEntry& e) {
+            e.obj = obj;
+            if (t < e.h.t || (t == e.h.t && gid < e.h.gid)) {
+                e.h.t = t; e.h.b0 = b0; e.h.b1 = b1; e.h.b2 = b2; e.h.gid = gid; e.ts = ts; e.det = det;
+            }
+        };
+        if (!object_cull_pass(cc.tmin, cc.bfar, m0)) ok = false;
+        else if (e0.obj == kNoHit || e0.obj == obj) keep(e0);
+        else if (e1.obj == kNoHit || e1.obj == obj) keep(e1);
+        else ok = false;
+        return ok ? bound : -1.0f; // a bound below every entry distance: the walk only drains its stack
+    });
+    if (!ok) return false;
+    if (e1.obj < e0.obj) { const BandEntry x = e0; e0 = e1; e1 = x; } // id order; an empty entry (kNoHit) sorts last
+    Hit best; best.t = FLT_MAX; best.gid = kNoHit; best.b0 = best.b1 = best.b2 = 0.0f;
+    float m = m0;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const BandEntry& e = k == 0 ? e0 : e1;
+        if (e.obj == kNoHit) continue;
+        cull_lookup(s, ray, e.obj, cc);
+        if (!object_cull_pass(cc.tmin, cc.bfar, m)) continue;
+        if (e.h.t > m) continue;
+        const float md = m * e.det;
+        if (e.det < 0 ? e.ts < md : e.ts > md) return false;
+        if (e.h.t < best.t) { best = e.h; m = e.h.t; }
+    }
+    ray.maxDist = m;
+    out = best;
+    return true;
 }
 
 // Closest hit with the exact in-order emulation inline for rays inside the tie band (rt_trace_rays,
