@@ -12,8 +12,7 @@ namespace {
 
 constexpr size_t kWorkBytes = sizeof(uint32_t) * 512;
 constexpr size_t kWfChunkDefault = 64u << 20;
-constexpr size_t kWfLaneMin = 2u << 20;   // samples below which another lane is not worth its launches
-constexpr int kWfLanesDefault = 3;        // the process has 4 hardware queues and one carries the copies: a 4th lane shares a queue and serialises
+constexpr int kWfLanesDefault = 3;        // most chunks in flight: the process has 4 hardware queues and one carries the copies, a 4th lane shares a queue and serialises
 constexpr size_t kCntBytes = sizeof(unsigned long long) * rt::kCounterSlots * rt::kCounterStride;
 
 thread_local std::string g_createError;
@@ -718,14 +717,15 @@ int rt_render(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* 
         const size_t perTile = 64 * (size_t)rnd->sampleCount;
         if (perTile >= (1ull << 31)) return fail(c, RT_ERR_INVALID, "sampleCount too large for one 8x8 tile of the wavefront workspace");
         if (tiles > 0) {
-            // lanes: one per kWfLaneMin samples up to optWfLanes; chunks: whole tiles, at most optWfChunk samples each
-            // (an explicit RT_OPT_WF_LANES is taken as given, up to one lane per tile)
+            // chunks: whole tiles, at most optWfChunk samples each.  lanes: a frame that fits one chunk runs in one
+            // lane (C2 7.6 / C4 15.9 / C5 16.2 ms against 8.0 / 16.7 / 17.0 ms in three: with the axis-parallel
+            // rays fixed the trace launches have no long tails left to hide); a frame of several chunks runs up
+            // to three at a time, each one's tail under the others' bulk (C3, 8 chunks: 10.8 / 11.3 / 11.5 Grays/s
+            // with 1 / 2 / 3 lanes).  An explicit RT_OPT_WF_LANES is taken as given, up to one lane per tile.
+            const size_t wantChunks = (tiles * perTile + c->optWfChunk - 1) / c->optWfChunk;
             int lanes = c->optWfLanes ? (int)(tiles < (size_t)c->optWfLanes ? tiles : (size_t)c->optWfLanes)
-                                      : (int)((tiles * perTile) / kWfLaneMin);
-            // default: 3 lanes for large scenes, where the tails of the trace launches are long (C4 4 lanes 27.3 /
-            // 3 lanes 22.6 / 2 lanes 24.3 ms), 2 for small ones (C2 9.9 / 9.3 / 8.8 ms)
-            const int maxLanes = c->optWfLanes ? c->optWfLanes : (c->built.nTris >= (1u << 18) ? kWfLanesDefault : 2);
-            lanes = lanes < 1 ? 1 : (lanes > maxLanes ? maxLanes : lanes);
+                                      : (int)(wantChunks < (size_t)kWfLanesDefault ? wantChunks : (size_t)kWfLanesDefault);
+            lanes = lanes < 1 ? 1 : lanes;
             size_t chunkTiles = (tiles + (size_t)lanes - 1) / (size_t)lanes;
             const size_t capTiles = c->optWfChunk / perTile ? c->optWfChunk / perTile : 1;
             if (chunkTiles > capTiles) chunkTiles = capTiles;
