@@ -478,3 +478,38 @@ def test_thousands_of_coincident_triangles(ctx):
     _, rid, _ = compare_modes(ctx, sc.flatten(), cam, st, modes=(0, 2))
     hit = rid[..., 0] == 0
     assert hit.any() and (rid[..., 2][hit] == 0).all()
+
+
+def test_axis_parallel_rays(ctx):
+    """Rays with exactly zero direction components that run inside the planes shared by many boxes
+    (cube faces on integer coordinates, origins on them): the box test must neither lose a hit nor,
+    as it once did through NaN slab distances, visit every box in the ray's plane."""
+    sc = Scene()
+    m = Material("a", (0.7, 0.5, 0.3, 1), 0.5, 0.1)
+    k = 0
+    for x in range(-6, 6):
+        for z in range(-6, 6):
+            c = Cube(); c.setPosition((x + 0.5, 0.5 * ((x + z) % 3), z + 0.5)); c.setMaterial(m); sc.addToScene(f"c{k}", c); k += 1
+    flat = sc.flatten()
+    rng = np.random.default_rng(3)
+    n = 30000
+    axes = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1],
+                     [0, -0.6, -0.8], [0.6, 0, 0.8], [-0.8, 0.6, 0], [0, -0.0, -1.0]], np.float32)
+    r = np.zeros((n, 8), np.float32)
+    r[:, :3] = np.round(rng.uniform(-8, 8, (n, 3)) * 2) / 2   # origins on the half-integer lattice: on faces and edges
+    r[:, 1] += 3.0 * (rng.random(n) < 0.3)
+    r[:, 3] = 100.0
+    r[:, 4:7] = axes[rng.integers(0, len(axes), n)]
+    ref = orc.trace_rays(flat, r)
+    for mode in (1, 0):
+        ctx.set_option(capi.OPT_TRAVERSAL, mode)
+        ctx.upload_scene(flat)
+        got = ctx.trace_rays(r)
+        assert np.array_equal(got, ref), mode
+    assert (ref[:, 0] != 0xFFFFFFFF).mean() > 0.1
+    # an axis-aligned camera on the symmetry plane: the centre column looks along x = 0 exactly
+    cam = Camera((0.0, 2.0, 14.0), (0.0, 0.0, 0.0, 1.0), 45.0, 1.0)
+    cam.setWidth(96); cam.setHeight(64); cam.calcRays()
+    st = RenderSettings(bounceCount=3, sampleCount=2, antiAliasingEnabled=False)
+    _, _, stats = compare_modes(ctx, flat, cam, st, modes=(0, 2))
+    assert stats.node_visits < 150 * stats.rays, "box tests per ray out of proportion: axis-parallel rays are visiting whole planes"
