@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "persistent"],
                     help="BVH render pipeline: per-bounce trace/shade launches (default) or the single persistent kernel")
     ap.add_argument("--wf-lanes", type=int, default=0, help="chunks in flight (HIP streams) of the wavefront pipeline (0 = library default)")
+    ap.add_argument("--builder", type=int, default=0, help="acceleration structure builder: 0 = PLOC (library default), 1 = radix tree")
     ap.add_argument("--wf-chunk", type=int, default=0, help="samples in flight per chunk of the wavefront pipeline (0 = library default)")
     args = ap.parse_args()
 
@@ -99,6 +100,8 @@ def main():
     ctx.set_option(capi.OPT_TRAVERSAL, 1 if args.brute else (0 if args.pipeline == "wavefront" else 2))
     if args.wf_lanes:
         ctx.set_option(capi.OPT_WF_LANES, args.wf_lanes)
+    if args.builder:
+        ctx.set_option(capi.OPT_BUILDER, args.builder)
     if args.wf_chunk:
         ctx.set_option(capi.OPT_WF_CHUNK, args.wf_chunk)
     t0 = time.time()

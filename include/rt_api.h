@@ -94,7 +94,10 @@ enum rt_option {
     RT_OPT_ACCUMULATE_STATS = 3, /* 1 = rt_render no longer zeroes the counters; setting it zeroes them once */
     RT_OPT_WF_CHUNK = 4,  /* samples in flight per chunk of the wavefront pipeline (0 = default, 64 Mi); the
                              workspace holds ~113 bytes per sample and lane */
-    RT_OPT_WF_LANES = 5   /* chunks in flight at once, each on its own HIP stream (0 = default: 3 from 2^18 triangles on, else 2; 1..4) */
+    RT_OPT_WF_LANES = 5,  /* chunks in flight at once, each on its own HIP stream (0 = default: one per chunk of the
+                             frame, at most 3; 1..4) */
+    RT_OPT_BUILDER = 6    /* acceleration structure built by rt_scene_commit: 0 = PLOC (default: slower commit, faster
+                             frames), 1 = Karras radix tree (scenes re-committed every frame).  Same pixels. */
 };
 
 /* ---- context ---- */

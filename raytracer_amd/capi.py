@@ -61,7 +61,7 @@ EXPORTS = [
     "rt_render", "rt_trace_rays", "rt_event_record", "rt_event_elapsed_ms", "rt_detmath_eval", "rt_version",
 ]
 
-OPT_TRAVERSAL, OPT_COUNTERS, OPT_ACCUMULATE_STATS, OPT_WF_CHUNK, OPT_WF_LANES = 1, 2, 3, 4, 5
+OPT_TRAVERSAL, OPT_COUNTERS, OPT_ACCUMULATE_STATS, OPT_WF_CHUNK, OPT_WF_LANES, OPT_BUILDER = 1, 2, 3, 4, 5, 6
 
 
 def lib():

@@ -61,7 +61,8 @@ struct rt_ctx {
     bool renderedOnce = false;
     float commitMs = 0.0f;
     int optTraversal = 0;
-    int optWfLanes = 0;                       // 0 = by scene size
+    int optWfLanes = 0;                       // 0 = by the number of chunks
+    int optBuilder = 0;                       // 0 = PLOC, 1 = radix tree
     size_t optWfChunk = kWfChunkDefault;     // samples in flight per chunk of the wavefront pipeline
     rt::WfLanes wf; size_t wfCapSlots = 0; int wfLevels = 0; int wfLanes = 0; // its lanes and their workspace (wf.bufs[0] owns the allocations)
     int optCounters = 0;
@@ -305,6 +306,9 @@ int rt_set_option(rt_ctx* c, int option, int value)
     case RT_OPT_WF_LANES:
         if (value < 0 || value > rt::kWfMaxLanes) return fail(c, RT_ERR_INVALID, "RT_OPT_WF_LANES takes 0 (default) .. 4");
         c->optWfLanes = value; return RT_OK;
+    case RT_OPT_BUILDER:
+        if (value < 0 || value > 1) return fail(c, RT_ERR_INVALID, "RT_OPT_BUILDER takes 0 (PLOC, default) or 1 (radix tree, fast rebuilds)");
+        c->optBuilder = value; return RT_OK;
     case RT_OPT_WF_CHUNK:
         if (value < 0) return fail(c, RT_ERR_INVALID, "RT_OPT_WF_CHUNK takes a sample count >= 0 (0 = default)");
         c->optWfChunk = value ? (size_t)value : kWfChunkDefault; return RT_OK;
@@ -561,7 +565,7 @@ int rt_scene_commit(rt_ctx* c, const rt_id* objects, const float* model16, const
     }
     hipEventRecord(c->slots[14], c->stream);
     std::string err;
-    const bool ok = rt::build_scene(dSegs, (int)segs.size(), dXf, (uint32_t)total, c->built, c->stream, err);
+    const bool ok = rt::build_scene(dSegs, (int)segs.size(), dXf, (uint32_t)total, c->built, c->optBuilder, c->stream, err);
     hipEventRecord(c->slots[15], c->stream);
     hipStreamSynchronize(c->stream);
     hipFree(dSegs); hipFree(dXf);

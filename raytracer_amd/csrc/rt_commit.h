@@ -37,7 +37,8 @@ struct BuiltScene {
     size_t arenaBytes = 0;
 };
 
-bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t nTris, BuiltScene& out,
+// builder: 0 = PLOC (quality), 1 = Karras radix tree (fast rebuilds)
+bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t nTris, BuiltScene& out, int builder,
                  hipStream_t stream, std::string& err);
 void free_scene(BuiltScene& s);
 

@@ -180,25 +180,36 @@ __global__ __launch_bounds__(256) void morton_kernel(const TriIsect* __restrict_
     vals[g] = g;
 }
 
-// leaf-order copy of the intersection records + leaf boxes (node index N-1+j)
-__global__ __launch_bounds__(256) void gather_kernel(const TriIsect* __restrict__ triRef, const uint32_t* __restrict__ order,
-                                                     uint32_t nTris, TriIsect* __restrict__ triLeaf,
-                                                     float* __restrict__ boxes)
+// boxes of the triangles in sorted (Morton) order: "node" N-1+j of the binary tree is sorted triangle j
+__global__ __launch_bounds__(256) void leafbox_kernel(const TriIsect* __restrict__ triRef, const uint32_t* __restrict__ order,
+                                                      uint32_t nTris, float* __restrict__ boxes)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nTris) return;
     const TriIsect t = triRef[order[j]];
-    // three copies, rotated for rays whose dominant axis kz is 0, 1, 2: (x,y,z) -> (kz+1, kz+2, kz) mod 3
-    TriIsect r = t;
-    r.v0x = t.v0y; r.v0y = t.v0z; r.v0z = t.v0x; r.v1x = t.v1y; r.v1y = t.v1z; r.v1z = t.v1x; r.v2x = t.v2y; r.v2y = t.v2z; r.v2z = t.v2x;
-    triLeaf[j] = r;
-    r.v0x = t.v0z; r.v0y = t.v0x; r.v0z = t.v0y; r.v1x = t.v1z; r.v1y = t.v1x; r.v1z = t.v1y; r.v2x = t.v2z; r.v2y = t.v2x; r.v2z = t.v2y;
-    triLeaf[(size_t)nTris + j] = r;
-    triLeaf[2 * (size_t)nTris + j] = t;
     float mn[3], mx[3];
     tri_box(t, mn, mx);
     float* b = boxes + 6 * (size_t)(nTris - 1 + j);
     b[0] = mn[0]; b[1] = mn[1]; b[2] = mn[2]; b[3] = mx[0]; b[4] = mx[1]; b[5] = mx[2];
+}
+
+// leaf-order copies of the intersection records: sorted triangle j goes to slot pos[j], the place the
+// collapse gave it (the leaves of the finished tree, left to right, so that a leaf is a run of slots)
+__global__ __launch_bounds__(256) void gather_kernel(const TriIsect* __restrict__ triRef, const uint32_t* __restrict__ order,
+                                                     const uint32_t* __restrict__ pos, uint32_t nTris,
+                                                     TriIsect* __restrict__ triLeaf)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nTris) return;
+    const TriIsect t = triRef[order[j]];
+    const size_t d = pos[j];
+    // three copies, rotated for rays whose dominant axis kz is 0, 1, 2: (x,y,z) -> (kz+1, kz+2, kz) mod 3
+    TriIsect r = t;
+    r.v0x = t.v0y; r.v0y = t.v0z; r.v0z = t.v0x; r.v1x = t.v1y; r.v1y = t.v1z; r.v1z = t.v1x; r.v2x = t.v2y; r.v2y = t.v2z; r.v2z = t.v2x;
+    triLeaf[d] = r;
+    r.v0x = t.v0z; r.v0y = t.v0x; r.v0z = t.v0y; r.v1x = t.v1z; r.v1y = t.v1x; r.v1z = t.v1y; r.v2x = t.v2z; r.v2y = t.v2x; r.v2z = t.v2y;
+    triLeaf[(size_t)nTris + d] = r;
+    triLeaf[2 * (size_t)nTris + d] = t;
 }
 
 // Karras 2012, "Maximizing parallelism in the construction of BVHs, octrees and k-d trees":
@@ -212,7 +223,7 @@ __device__ __forceinline__ int delta(const unsigned long long* __restrict__ keys
 }
 
 __global__ __launch_bounds__(256) void karras_kernel(const unsigned long long* __restrict__ keys, int n, int2* __restrict__ children,
-                                                     int2* __restrict__ ranges, int* __restrict__ parent)
+                                                     int* __restrict__ count, int* __restrict__ parent)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
@@ -236,7 +247,7 @@ __global__ __launch_bounds__(256) void karras_kernel(const unsigned long long* _
     const int left = (first == gamma) ? ~gamma : gamma;
     const int right = (last == gamma + 1) ? ~(gamma + 1) : gamma + 1;
     children[i] = make_int2(left, right);
-    ranges[i] = make_int2(first, last);
+    count[i] = last - first + 1;
     // parent of internal node c: parent[c]; of leaf j: parent[n - 1 + j] (the numbering of `boxes`)
     parent[left < 0 ? n - 1 + (~left) : left] = i;
     parent[right < 0 ? n - 1 + (~right) : right] = i;
@@ -298,27 +309,25 @@ __global__ __launch_bounds__(256) void fit_frontier_kernel(const int2* __restric
 // the binary node's two children, with the larger (by surface area) internal ones replaced by
 // their own children until four slots are used.  A binary subtree of at most kLeafMax triangles
 // becomes a leaf (its triangles are contiguous in leaf order).
-__device__ __forceinline__ bool is_leaf_subtree(int c, const int2* __restrict__ ranges)
-{
-    if (c < 0) return true;
-    const int2 r = ranges[c];
-    return r.y - r.x + 1 <= kLeafMax;
-}
+__device__ __forceinline__ int tris_under(int c, const int* __restrict__ count) { return c < 0 ? 1 : count[c]; }
+__device__ __forceinline__ bool is_leaf_subtree(int c, const int* __restrict__ count) { return tris_under(c, count) <= kLeafMax; }
 
 __device__ __forceinline__ const float* box_of(int c, const float* __restrict__ boxes, int nLeaves)
 {
     return boxes + 6 * (size_t)(c < 0 ? nLeaves - 1 + (~c) : c);
 }
 
-__global__ __launch_bounds__(256) void collapse_kernel(const int2* __restrict__ children, const int2* __restrict__ ranges,
+__global__ __launch_bounds__(256) void collapse_kernel(const int2* __restrict__ children, const int* __restrict__ count,
                                                        const float* __restrict__ boxes, int nLeaves,
-                                                       const int2* __restrict__ qIn, uint32_t qCount,
-                                                       int2* __restrict__ qOut, uint32_t* __restrict__ qOutCount,
-                                                       uint32_t* __restrict__ nodeCount, BvhNode* __restrict__ nodes)
+                                                       const int2* __restrict__ qIn, const uint32_t* __restrict__ firstIn, uint32_t qCount,
+                                                       int2* __restrict__ qOut, uint32_t* __restrict__ firstOut, uint32_t* __restrict__ qOutCount,
+                                                       uint32_t* __restrict__ nodeCount, BvhNode* __restrict__ nodes,
+                                                       uint32_t* __restrict__ pos)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= qCount) return;
     const int2 task = qIn[i];
+    uint32_t first = firstIn[i]; // leaf slot of the subtree's leftmost triangle
     int c0, c1, c2 = 0, c3 = 0, n = 2;
     { const int2 c = children[task.x]; c0 = c.x; c1 = c.y; }
     for (int iter = 0; iter < 2; iter++) {
@@ -327,7 +336,7 @@ __global__ __launch_bounds__(256) void collapse_kernel(const int2* __restrict__ 
         for (int k = 0; k < 4; k++) {
             if (k >= n) break;
             const int c = k == 0 ? c0 : (k == 1 ? c1 : (k == 2 ? c2 : c3));
-            if (is_leaf_subtree(c, ranges)) continue;
+            if (is_leaf_subtree(c, count)) continue;
             const float* b = boxes + 6 * (size_t)c;
             const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
             float A = dx * dy + dy * dz + dz * dx;
@@ -346,7 +355,7 @@ __global__ __launch_bounds__(256) void collapse_kernel(const int2* __restrict__ 
     const int cs[4] = { c0, c1, c2, c3 };
     int m = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) if (k < n && !is_leaf_subtree(cs[k], ranges)) m++;
+    for (int k = 0; k < 4; k++) if (k < n && !is_leaf_subtree(cs[k], count)) m++;
     uint32_t base = 0, qbase = 0;
     if (m > 0) { base = atomicAdd(nodeCount, (uint32_t)m); qbase = atomicAdd(qOutCount, (uint32_t)m); }
     // node box = union of the child boxes, clamped so that the extents stay finite
@@ -396,19 +405,24 @@ __global__ __launch_bounds__(256) void collapse_kernel(const int2* __restrict__ 
                 ql[a] |= (uint32_t)q0 << (8 * k);
                 qh[a] |= (uint32_t)q1 << (8 * k);
             }
-            if (c < 0) {
-                nd.child[k] = ~(int32_t)(((uint32_t)(~c) << 3) | 1u);
-            } else {
-                const int2 r = ranges[c];
-                const int count = r.y - r.x + 1;
-                if (count <= kLeafMax) {
-                    nd.child[k] = ~(int32_t)(((uint32_t)r.x << 3) | (uint32_t)count);
-                } else {
-                    nd.child[k] = (int32_t)(base + (uint32_t)j);
-                    qOut[qbase + (uint32_t)j] = make_int2(c, (int)(base + (uint32_t)j));
-                    j++;
+            const int under = tris_under(c, count);
+            if (under <= kLeafMax) {
+                // a leaf: its triangles take the slots first .. first + under - 1, left to right
+                nd.child[k] = ~(int32_t)((first << 3) | (uint32_t)under);
+                int stk[8]; int sp = 0; stk[sp++] = c;
+                uint32_t p = first;
+                while (sp > 0) {
+                    const int x = stk[--sp];
+                    if (x < 0) pos[~x] = p++;
+                    else { const int2 cc = children[x]; stk[sp++] = cc.y; stk[sp++] = cc.x; }
                 }
+            } else {
+                nd.child[k] = (int32_t)(base + (uint32_t)j);
+                qOut[qbase + (uint32_t)j] = make_int2(c, (int)(base + (uint32_t)j));
+                firstOut[qbase + (uint32_t)j] = first;
+                j++;
             }
+            first += (uint32_t)under;
         } else {
             // unused slot: inverted box, empty leaf
 #pragma unroll
@@ -451,6 +465,106 @@ __global__ void emit_single_kernel(const float* __restrict__ boxes, BvhNode* __r
     nodes[0] = nd;
 }
 
+// ---- PLOC: parallel locally-ordered clustering (Meister & Bittner 2018) ----
+// The quality builder.  The clusters start as the triangles in Morton order; every pass each cluster
+// looks kPlocRadius places left and right for the neighbour whose union with it has the smallest
+// surface area, mutual choices merge into a new binary node, and the survivors are compacted in order.
+// Measured against the radix tree above (same collapse, same traversal): see DESIGN.md section 4.
+// A cluster is named like a child: >= 0 internal node, < 0 the sorted triangle ~c.
+#ifndef RT_PLOC_RADIUS
+#define RT_PLOC_RADIUS 16
+#endif
+constexpr int kPlocRadius = RT_PLOC_RADIUS;
+
+__global__ __launch_bounds__(256) void ploc_init_kernel(int* __restrict__ cl, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cl[i] = ~i;
+}
+
+// nn[i] = the neighbour within the radius that minimises (area of the union, distance in places, parity of
+// the lower place, lower place): a total order on pairs that both ends see alike, so the best pair overall
+// is always mutual and every pass merges at least once.  Non-finite areas count as FLT_MAX.
+__global__ __launch_bounds__(256) void ploc_nn_kernel(const int* __restrict__ cl, int m, const float* __restrict__ boxes, int nLeaves,
+                                                      int* __restrict__ nn)
+{
+    __shared__ float sb[6][256 + 2 * kPlocRadius];
+    const int base = (int)(blockIdx.x * 256u) - kPlocRadius;
+    for (int t = threadIdx.x; t < 256 + 2 * kPlocRadius; t += 256) {
+        const int g = base + t;
+        if (g >= 0 && g < m) {
+            const float* b = box_of(cl[g], boxes, nLeaves);
+#pragma unroll
+            for (int k = 0; k < 6; k++) sb[k][t] = b[k];
+        }
+    }
+    __syncthreads();
+    const int i = (int)(blockIdx.x * 256u) + (int)threadIdx.x;
+    if (i >= m) return;
+    const int ti = (int)threadIdx.x + kPlocRadius;
+    const float a0 = sb[0][ti], a1 = sb[1][ti], a2 = sb[2][ti], a3 = sb[3][ti], a4 = sb[4][ti], a5 = sb[5][ti];
+    float bestA = 0.0f; int bestJ = -1;
+    for (int d = -kPlocRadius; d <= kPlocRadius; d++) {
+        const int j = i + d;
+        if (d == 0 || j < 0 || j >= m) continue;
+        const int tj = ti + d;
+        const float dx = __builtin_fmaxf(a3, sb[3][tj]) - __builtin_fminf(a0, sb[0][tj]);
+        const float dy = __builtin_fmaxf(a4, sb[4][tj]) - __builtin_fminf(a1, sb[1][tj]);
+        const float dz = __builtin_fmaxf(a5, sb[5][tj]) - __builtin_fminf(a2, sb[2][tj]);
+        float A = dx * dy + dy * dz + dz * dx;
+        if (!(A < FLT_MAX)) A = FLT_MAX;
+        bool take = bestJ < 0 || A < bestA;
+        if (!take && A == bestA) {
+            // equal areas (coincident or gridded geometry): the closer place first, then pairs that start on an
+            // even place, then the lower pair -- with everything equal the places pair up (0,1), (2,3), ... and the
+            // pass halves the clusters instead of merging one pair
+            const int d1 = d < 0 ? -d : d, d2 = bestJ < i ? i - bestJ : bestJ - i;
+            const int lo1 = i < j ? i : j, lo2 = i < bestJ ? i : bestJ;
+            take = d1 < d2 || (d1 == d2 && ((lo1 & 1) < (lo2 & 1) || ((lo1 & 1) == (lo2 & 1) && lo1 < lo2)));
+        }
+        if (take) { bestA = A; bestJ = j; }
+    }
+    nn[i] = bestJ;
+}
+
+// flags[i]: low word 1 if cluster i survives the pass (alone, or as the lower end of a merging pair),
+// high word 1 if it is that lower end (a new node is created in its place)
+__global__ __launch_bounds__(256) void ploc_flag_kernel(const int* __restrict__ nn, int m, unsigned long long* __restrict__ flags)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const int j = nn[i];
+    const bool mutual = j >= 0 && nn[j] == i;
+    flags[i] = mutual ? (i < j ? 0x100000001ull : 0ull) : 1ull;
+}
+
+__global__ __launch_bounds__(256) void ploc_merge_kernel(const int* __restrict__ cl, const int* __restrict__ nn, int m,
+                                                         const unsigned long long* __restrict__ flags,
+                                                         const unsigned long long* __restrict__ prefix, int nodeBase, int nLeaves,
+                                                         int2* __restrict__ children, int* __restrict__ count, float* __restrict__ boxes,
+                                                         int* __restrict__ out, uint32_t* __restrict__ totals)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const unsigned long long f = flags[i], pre = prefix[i];
+    if (i == m - 1) { totals[0] = (uint32_t)(pre + f); totals[1] = (uint32_t)((pre + f) >> 32); }
+    if ((f & 1ull) == 0ull) return;
+    int c = cl[i];
+    if (f >> 32) {
+        const int d = cl[nn[i]];
+        const int id = nodeBase + (int)(pre >> 32);
+        const float* a = box_of(c, boxes, nLeaves);
+        const float* b = box_of(d, boxes, nLeaves);
+        float* o = boxes + 6 * (size_t)id;
+        o[0] = __builtin_fminf(a[0], b[0]); o[1] = __builtin_fminf(a[1], b[1]); o[2] = __builtin_fminf(a[2], b[2]);
+        o[3] = __builtin_fmaxf(a[3], b[3]); o[4] = __builtin_fmaxf(a[4], b[4]); o[5] = __builtin_fmaxf(a[5], b[5]);
+        children[id] = make_int2(c, d); // the lower-placed cluster stays on the left
+        count[id] = tris_under(c, count) + tris_under(d, count);
+        c = id;
+    }
+    out[(uint32_t)pre] = c;
+}
+
 #define RT_HIP(call)                                                                                         \
     do {                                                                                                     \
         hipError_t e_ = (call);                                                                              \
@@ -463,7 +577,7 @@ static inline uint32_t host_f2o(float f)
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t nTris, BuiltScene& out,
+bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t nTris, BuiltScene& out, int builder,
                  hipStream_t stream, std::string& err)
 {
     out.nTris = nTris;
@@ -490,8 +604,8 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
     unsigned long long *keysA = nullptr, *keysB = nullptr;
     int2 *queueA = nullptr, *queueB = nullptr;
     float* boxes = nullptr;
-    int2 *children = nullptr, *ranges = nullptr;
-    int* parent = nullptr;
+    int2* children = nullptr;
+    int *count = nullptr, *parent = nullptr;
     void* sortTmp = nullptr;
     auto cleanup = [&]() {};
 #define RT_HIPC(call)                                                                                        \
@@ -500,15 +614,18 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
         if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); cleanup(); return false; } \
     } while (0)
 
-    size_t tmpBytes = 0;
+    size_t tmpBytes = 0, scanBytes = 0;
     RT_HIPC(rocprim::radix_sort_pairs(nullptr, tmpBytes, keysA, keysB, valsA, valsB, (size_t)nTris, 0, 63, stream));
+    RT_HIPC(rocprim::exclusive_scan(nullptr, scanBytes, keysA, keysB, 0ull, (size_t)nTris, rocprim::plus<unsigned long long>(), stream));
+    const size_t sortBytes = tmpBytes;
+    if (scanBytes > tmpBytes) tmpBytes = scanBytes;
     {
         const size_t n = nTris, ni = nInternal;
         size_t off = 0;
         auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
         const size_t oBounds = take(6 * sizeof(uint32_t)), oKeysA = take(8 * n), oKeysB = take(8 * n), oValsA = take(4 * n),
                      oValsB = take(4 * n), oSort = take(tmpBytes ? tmpBytes : 16), oBoxes = take(sizeof(float) * 6 * 2 * n),
-                     oChildren = take(sizeof(int2) * ni), oRanges = take(sizeof(int2) * ni), oDone = take(4 * ni),
+                     oChildren = take(sizeof(int2) * ni), oCount = take(sizeof(int) * ni), oDone = take(4 * ni),
                      oRemaining = take(4), oParent = take(sizeof(int) * (2 * n)), oQueueA = take(sizeof(int2) * ni), oQueueB = take(sizeof(int2) * ni);
         if (off > out.arenaBytes) {
             hipFree(out.arena); out.arena = nullptr; out.arenaBytes = 0;
@@ -518,7 +635,7 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
         char* base = (char*)out.arena;
         dBounds = (uint32_t*)(base + oBounds); keysA = (unsigned long long*)(base + oKeysA); keysB = (unsigned long long*)(base + oKeysB);
         valsA = (uint32_t*)(base + oValsA); valsB = (uint32_t*)(base + oValsB); sortTmp = base + oSort; boxes = (float*)(base + oBoxes);
-        children = (int2*)(base + oChildren); ranges = (int2*)(base + oRanges); done = (uint32_t*)(base + oDone);
+        children = (int2*)(base + oChildren); count = (int*)(base + oCount); done = (uint32_t*)(base + oDone);
         remaining = (uint32_t*)(base + oRemaining); parent = (int*)(base + oParent); queueA = (int2*)(base + oQueueA); queueB = (int2*)(base + oQueueB);
     }
 
@@ -565,13 +682,21 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
     hipLaunchKernelGGL(morton_kernel, dim3(grid), dim3(256), 0, stream, out.triRef, nTris, dBounds, plan, keysA, valsA);
     RT_HIPC(hipGetLastError());
 
-    RT_HIPC(rocprim::radix_sort_pairs(sortTmp, tmpBytes, keysA, keysB, valsA, valsB, (size_t)nTris, 0, 63, stream));
+    {
+        size_t bytes = sortBytes;
+        RT_HIPC(rocprim::radix_sort_pairs(sortTmp, bytes, keysA, keysB, valsA, valsB, (size_t)nTris, 0, 63, stream));
+    }
+    // from here on: valsB = sorted order, keysB = sorted keys; keysA and valsA are free
+    uint32_t* pos = (uint32_t*)keysA;      // final leaf slot of sorted triangle j (written by the collapse)
 
-    hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(256), 0, stream, out.triRef, valsB, nTris, out.triLeaf, boxes);
+    hipLaunchKernelGGL(leafbox_kernel, dim3(grid), dim3(256), 0, stream, out.triRef, valsB, nTris, boxes);
     RT_HIPC(hipGetLastError());
 
     if (nTris == 1) {
         // boxes[0..5] of "node N-1+0" = index 0
+        const uint32_t zero = 0;
+        RT_HIPC(hipMemcpyAsync(pos, &zero, sizeof(zero), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(gather_kernel, dim3(1), dim3(256), 0, stream, out.triRef, valsB, pos, nTris, out.triLeaf);
         hipLaunchKernelGGL(emit_single_kernel, dim3(1), dim3(1), 0, stream, boxes, out.nodes);
         RT_HIPC(hipGetLastError());
         RT_HIPC(hipStreamSynchronize(stream));
@@ -581,47 +706,84 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
 
     const int nInt = (int)nTris - 1;
     const uint32_t gridI = ((uint32_t)nInt + 255) / 256;
-    RT_HIPC(hipMemsetAsync(done, 0, sizeof(uint32_t) * (size_t)nInt, stream));
-    hipLaunchKernelGGL(karras_kernel, dim3(gridI), dim3(256), 0, stream, keysB, (int)nTris, children, ranges, parent);
-    RT_HIPC(hipGetLastError());
-
-    // box fit: frontiers ping-pong in the collapse's queues (free until then); `done` counts arrivals
-    {
+    int root = 0;
+    if (builder == 1) {
+        // ---- radix tree (fast rebuilds)
+        RT_HIPC(hipMemsetAsync(done, 0, sizeof(uint32_t) * (size_t)nInt, stream));
+        hipLaunchKernelGGL(karras_kernel, dim3(gridI), dim3(256), 0, stream, keysB, (int)nTris, children, count, parent);
+        RT_HIPC(hipGetLastError());
+        // box fit: frontiers ping-pong in the collapse's queues (free until then); `done` counts arrivals
         int* cur = (int*)queueA;
         int* next = (int*)queueB;
         RT_HIPC(hipMemsetAsync(remaining, 0, sizeof(uint32_t), stream));
         hipLaunchKernelGGL(fit_leaves_kernel, dim3(grid), dim3(256), 0, stream, parent, (int)nTris, done, cur, remaining);
         RT_HIPC(hipGetLastError());
-        uint32_t count = 0;
+        uint32_t cnt = 0;
         for (uint32_t pass = 0;; pass++) {
-            RT_HIPC(hipMemcpyAsync(&count, remaining, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            RT_HIPC(hipMemcpyAsync(&cnt, remaining, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             RT_HIPC(hipStreamSynchronize(stream));
-            if (count == 0) break;
+            if (cnt == 0) break;
             if (pass > (uint32_t)nInt) { err = "BVH box fit did not terminate"; cleanup(); return false; }
             RT_HIPC(hipMemsetAsync(remaining, 0, sizeof(uint32_t), stream));
-            hipLaunchKernelGGL(fit_frontier_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, children, parent, (int)nTris, boxes,
-                               done, cur, count, next, remaining);
+            hipLaunchKernelGGL(fit_frontier_kernel, dim3((cnt + 255) / 256), dim3(256), 0, stream, children, parent, (int)nTris, boxes,
+                               done, cur, cnt, next, remaining);
             RT_HIPC(hipGetLastError());
             int* t = cur; cur = next; next = t;
         }
+    } else {
+        // ---- PLOC: clusters ping-pong in the collapse's queues, neighbours in `parent`, flags and their
+        // prefix sums in the two key arrays (the sort is done with them), totals in the bounds cell
+        int* cur = (int*)queueA;
+        int* next = (int*)queueB;
+        int* nn = parent;
+        unsigned long long *flags = keysA, *prefix = keysB;
+        uint32_t* totals = dBounds;
+        hipLaunchKernelGGL(ploc_init_kernel, dim3(grid), dim3(256), 0, stream, cur, (int)nTris);
+        int m = (int)nTris, nodeBase = 0;
+        for (int pass = 0; m > 1; pass++) {
+            if (pass > (int)nTris) { err = "PLOC did not terminate"; cleanup(); return false; }
+            const uint32_t g = ((uint32_t)m + 255) / 256;
+            hipLaunchKernelGGL(ploc_nn_kernel, dim3(g), dim3(256), 0, stream, cur, m, boxes, (int)nTris, nn);
+            hipLaunchKernelGGL(ploc_flag_kernel, dim3(g), dim3(256), 0, stream, nn, m, flags);
+            RT_HIPC(hipGetLastError());
+            size_t bytes = scanBytes;
+            RT_HIPC(rocprim::exclusive_scan(sortTmp, bytes, flags, prefix, 0ull, (size_t)m, rocprim::plus<unsigned long long>(), stream));
+            hipLaunchKernelGGL(ploc_merge_kernel, dim3(g), dim3(256), 0, stream, cur, nn, m, flags, prefix, nodeBase, (int)nTris, children,
+                               count, boxes, next, totals);
+            RT_HIPC(hipGetLastError());
+            uint32_t tot[2] = { 0, 0 };
+            RT_HIPC(hipMemcpyAsync(tot, totals, sizeof(tot), hipMemcpyDeviceToHost, stream));
+            RT_HIPC(hipStreamSynchronize(stream));
+            if (tot[1] == 0 || (int)tot[0] >= m) { err = "PLOC pass merged nothing"; cleanup(); return false; }
+            m = (int)tot[0]; nodeBase += (int)tot[1];
+            int* t = cur; cur = next; next = t;
+        }
+        if (nodeBase != nInt) { err = "PLOC node count mismatch"; cleanup(); return false; }
+        root = nInt - 1; // the last node created
     }
 
-    // collapse: `remaining` doubles as the next level's task count, done[0] as the node allocator
-    const int2 rootTask = make_int2(0, 0);
-    const uint32_t one = 1;
+    // collapse: `remaining` doubles as the next level's task count, done[0] as the node allocator; the
+    // leaf slot of each task's leftmost triangle travels in two arrays beside the queues
+    uint32_t *firstA = valsA, *firstB = (uint32_t*)parent + nTris;
+    const int2 rootTask = make_int2(root, 0);
+    const uint32_t one = 1, zero = 0;
     RT_HIPC(hipMemcpyAsync(queueA, &rootTask, sizeof(rootTask), hipMemcpyHostToDevice, stream));
+    RT_HIPC(hipMemcpyAsync(firstA, &zero, sizeof(zero), hipMemcpyHostToDevice, stream));
     RT_HIPC(hipMemcpyAsync(done, &one, sizeof(one), hipMemcpyHostToDevice, stream));
     uint32_t qCount = 1;
     for (int level = 0; qCount > 0; level++) {
         if (level > 4 * kStackDepth) { err = "BVH collapse did not terminate"; cleanup(); return false; }
         RT_HIPC(hipMemsetAsync(remaining, 0, sizeof(uint32_t), stream));
-        hipLaunchKernelGGL(collapse_kernel, dim3((qCount + 255) / 256), dim3(256), 0, stream, children, ranges, boxes,
-                           (int)nTris, queueA, qCount, queueB, remaining, done, out.nodes);
+        hipLaunchKernelGGL(collapse_kernel, dim3((qCount + 255) / 256), dim3(256), 0, stream, children, count, boxes,
+                           (int)nTris, queueA, firstA, qCount, queueB, firstB, remaining, done, out.nodes, pos);
         RT_HIPC(hipGetLastError());
         RT_HIPC(hipMemcpyAsync(&qCount, remaining, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         RT_HIPC(hipStreamSynchronize(stream));
         int2* t = queueA; queueA = queueB; queueB = t;
+        uint32_t* tf = firstA; firstA = firstB; firstB = tf;
     }
+    hipLaunchKernelGGL(gather_kernel, dim3(grid), dim3(256), 0, stream, out.triRef, valsB, pos, nTris, out.triLeaf);
+    RT_HIPC(hipGetLastError());
     uint32_t nNodes = 0;
     RT_HIPC(hipMemcpyAsync(&nNodes, done, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     RT_HIPC(hipStreamSynchronize(stream));
