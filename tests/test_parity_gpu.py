@@ -169,12 +169,16 @@ def test_trace_rays_random_and_adversarial(ctx):
     rng = np.random.default_rng(1)
     rays = np.concatenate([random_rays(rng, 60000), adversarial_rays(flat, rng, 60000)])
     ref = orc.trace_rays(flat, rays)
-    for mode in (1, 0):
-        ctx.set_option(capi.OPT_TRAVERSAL, mode)
-        ctx.upload_scene(flat)
-        got = ctx.trace_rays(rays)
-        bad = np.nonzero((got != ref).any(axis=1))[0]
-        assert bad.size == 0, (mode, bad[:5], got[bad[:5]], ref[bad[:5]])
+    try:
+        for mode, builder in ((1, 0), (0, 0), (0, 1)):
+            ctx.set_option(capi.OPT_TRAVERSAL, mode)
+            ctx.set_option(capi.OPT_BUILDER, builder)
+            ctx.upload_scene(flat)
+            got = ctx.trace_rays(rays)
+            bad = np.nonzero((got != ref).any(axis=1))[0]
+            assert bad.size == 0, (mode, builder, bad[:5], got[bad[:5]], ref[bad[:5]])
+    finally:
+        ctx.set_option(capi.OPT_BUILDER, 0)
     assert (ref[:, 0] != 0xFFFFFFFF).mean() > 0.3
 
 
@@ -400,7 +404,8 @@ def test_custom_model_from_asset_files(ctx, tmp_path):
     assert (rid[..., 0] != 0xFFFFFFFF).mean() > 0.05 and not (rid[..., 0] == 1).any()
 
 
-def test_dynamic_scene_recommit_matches_oracle(ctx):
+@pytest.mark.parametrize("builder", [0, 1], ids=["ploc", "radix-tree"])
+def test_dynamic_scene_recommit_matches_oracle(ctx, builder):
     """the reference rebuilds its instance table every frame (Scene.cpp:3-29).  Here the
     transforms are re-committed on the handles already uploaded (no mesh / texture re-upload; the record
     arrays and the build's scratch arena are reused) and the frame must match the oracle's for the moved scene."""
@@ -409,6 +414,7 @@ def test_dynamic_scene_recommit_matches_oracle(ctx):
     st = RenderSettings(bounceCount=3, sampleCount=2)
     flat = sc.flatten()
     ctx.set_option(capi.OPT_TRAVERSAL, 0)
+    ctx.set_option(capi.OPT_BUILDER, builder)   # 1: the builder meant for scenes re-committed every frame
     ids = ctx.upload_scene(flat)
     ctx.set_camera_rays(cam.preTransformRays)
     fb = ctx.framebuffer(cam.width, cam.height, ids=True)
@@ -428,6 +434,7 @@ def test_dynamic_scene_recommit_matches_oracle(ctx):
         assert np.array_equal(img, ref)
     print("commit ms: first %.2f, re-commit %.2f" % (first_ms, ctx.stats().commit_ms))
     ctx.framebuffer_destroy(fb)
+    ctx.set_option(capi.OPT_BUILDER, 0)
 
 
 @pytest.mark.parametrize("lanes,chunk", [(1, 1024), (3, 2048), (4, 1 << 20)])
@@ -475,9 +482,14 @@ def test_thousands_of_coincident_triangles(ctx):
     sc.addToScene("ball", s)
     cam = Camera((0.2, 0.1, 5.0)); cam.setWidth(96); cam.setHeight(72); cam.calcRays()
     st = RenderSettings(bounceCount=3, sampleCount=2)
-    _, rid, _ = compare_modes(ctx, sc.flatten(), cam, st, modes=(0, 2))
-    hit = rid[..., 0] == 0
-    assert hit.any() and (rid[..., 2][hit] == 0).all()
+    for builder in (0, 1):   # equal boxes everywhere: PLOC's tie-break has to pair them up, the radix tree splits by position
+        ctx.set_option(capi.OPT_BUILDER, builder)
+        try:
+            _, rid, _ = compare_modes(ctx, sc.flatten(), cam, st, modes=(0, 2))
+        finally:
+            ctx.set_option(capi.OPT_BUILDER, 0)
+        hit = rid[..., 0] == 0
+        assert hit.any() and (rid[..., 2][hit] == 0).all()
 
 
 def test_axis_parallel_rays(ctx):
