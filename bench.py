@@ -179,7 +179,9 @@ def main():
         # (trace: ray 32 + queue 4 in, hit 20 out; shade: ray 32 + hit 20 + state 32 + queue 4 in,
         # ray 32 + state 32 + queue 4 out) and per sample 16 + 1 bytes of result out and in again
         state_b = (32 + 4 + 20) + (32 + 20 + 32 + 4) + (32 + 32 + 4) if args.pipeline == "wavefront" and not args.brute else 0.0
-        alg_bytes = (s.node_visits * node_b + s.tri_tests * tri_b + s.hits * (shade_b + tex_per_hit)
+        # a packet of 64 camera rays fetches a node once (scalar load) and tests it per ray
+        node_fetches = s.node_visits - s.packet_node_tests + s.packet_node_fetches
+        alg_bytes = (node_fetches * node_b + s.tri_tests * tri_b + s.hits * (shade_b + tex_per_hit)
                      + rays_local * state_b + samples_local * (64.0 + (34.0 if state_b else 0.0)) + pix_local * 16.0)
         alg_flops = s.node_visits * 44.0 + s.tri_tests * 45.0 + s.hits * 300.0 + samples_local * 60.0
         achieved_gbs = alg_bytes / launches / (kernel_ms * 1e-3) / 1e9
@@ -218,6 +220,7 @@ def main():
                          else ("path_kernel + redo" if not args.brute else "render_kernel (brute force)"),
                          "kernel_ms": kernel_ms,
                          "bytes_per_ray": alg_bytes / max(1, rays_local), "nodes_per_ray": s.node_visits / max(1, rays_local),
+                         "node_fetches_per_ray": node_fetches / max(1, rays_local),
                          "tris_per_ray": s.tri_tests / max(1, rays_local), "slow_path_frac": s.slow_path / max(1, rays_local),
                          "valu": {"achieved": achieved_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": achieved_tf / FP32_PEAK_TFLOPS, "flop_per_ray": alg_flops / max(1, rays_local)}},

@@ -83,8 +83,9 @@ typedef struct {
     uint64_t node_visits;  /* BVH node visits of the last rt_render */
     uint64_t tri_tests;    /* triangle tests of the last rt_render */
     uint64_t hits;         /* closest-hit queries that hit and were shaded */
-    uint64_t idle_node_lanes; /* diagnostic builds (-DRT_UTIL_COUNTERS): idle lane slots in the node loop */
-    uint64_t idle_tri_lanes;  /* ... and in the triangle loop; 0 in the shipped library */
+    uint64_t packet_node_tests;   /* the part of node_visits done by camera-ray packets (one test per ray and node) ... */
+    uint64_t packet_node_fetches; /* ... and the node fetches behind them: a packet of 64 rays fetches a node once.
+                                     (Diagnostic builds, -DRT_UTIL_COUNTERS / _TIMERS, report other tallies in these two.) */
 } rt_stats;
 
 enum rt_option {

@@ -49,7 +49,11 @@ class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("kernel_ms", C.c_float), ("triangles", C.c_uint32), ("bvh_nodes", C.c_uint32),
                 ("commit_ms", C.c_float), ("slow_path", C.c_uint64), ("node_visits", C.c_uint64),
                 ("tri_tests", C.c_uint64), ("hits", C.c_uint64),
-                ("idle_node_lanes", C.c_uint64), ("idle_tri_lanes", C.c_uint64)]
+                ("packet_node_tests", C.c_uint64), ("packet_node_fetches", C.c_uint64)]
+
+    # diagnostic builds of the library report other tallies in the last two slots (tools/)
+    idle_node_lanes = property(lambda self: self.packet_node_tests)
+    idle_tri_lanes = property(lambda self: self.packet_node_fetches)
 
 
 EXPORTS = [

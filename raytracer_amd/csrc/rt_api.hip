@@ -341,7 +341,7 @@ int rt_get_stats(rt_ctx* c, rt_stats* out)
             for (int k = 0; k < 8; k++) sum[k] += c->hCounters[(size_t)sl * rt::kCounterStride + k];
         out->rays = sum[0]; out->slow_path = sum[1];
         out->node_visits = sum[2]; out->tri_tests = sum[3]; out->hits = sum[4];
-        out->idle_node_lanes = sum[5]; out->idle_tri_lanes = sum[6];
+        out->packet_node_tests = sum[5]; out->packet_node_fetches = sum[6];
         float ms = 0.0f;
         RT_CHECK(c, hipEventElapsedTime(&ms, c->evBegin, c->evEnd));
         out->kernel_ms = ms;

@@ -106,6 +106,9 @@ __device__ __forceinline__ V4 bilerp(const V4& t00, const V4& t10, const V4& t01
 __device__ __forceinline__ V4 texel8(const DevTexture& t, int x, int y)
 {
     const uchar4 p = t.data[(size_t)y * (size_t)t.w + (size_t)x];
+#ifdef RT_ABLATE_TEXDIV
+    return mk4((float)p.x * 0.003921569f, (float)p.y * 0.003921569f, (float)p.z * 0.003921569f, (float)p.w * 0.003921569f); // timing-only build
+#endif
     return mk4((float)p.x / 255.0f, (float)p.y / 255.0f, (float)p.z / 255.0f, (float)p.w / 255.0f);
 }
 // Material.cu:224-228: normalized coordinates, linear, clamp
@@ -1055,6 +1058,10 @@ __global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const R
                     uint32_t k[4];
                     node_test(T.br, N0, N1, N2, T.bound, k);
                     st.bvh.nodes += active ? 1u : 0u;
+#if !defined(RT_PHASE_TIMERS) && !defined(RT_LOOP_TIMERS) && !defined(RT_UTIL_COUNTERS)
+                    st.bvh.idleA += active ? 1u : 0u;   // rt_stats.packet_node_tests / packet_node_fetches
+                    st.bvh.idleB += lane == 0 ? 1u : 0u;
+#endif
 #ifdef RT_PHASE_TIMERS
                     dbgNodes++; dbgSp = sp > dbgSp ? sp : dbgSp;
 #endif
