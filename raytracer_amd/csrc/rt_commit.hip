@@ -3,9 +3,9 @@
 //
 // Replaces the per-frame instance table of Scene::getGPUObjectDataVector (Scene.cpp:3-29) and the
 // pointer tables of DisplayObject::sendToGPU (DisplayObject.cpp:30-81).  The reference builds no
-// acceleration structure; this file adds one (LBVH: 63-bit Morton codes -> radix sort -> Karras
-// radix tree -> level-synchronous box fit -> top-down collapse into 128-byte four-wide nodes with up
-// to kLeafMax triangles per leaf).  World-space positions and normals are produced with the reference's own expressions
+// acceleration structure; this file adds one (63-bit Morton codes -> radix sort -> binary tree by PLOC,
+// or a Karras radix tree + frontier box fit for fast rebuilds -> top-down collapse into 64-byte four-wide
+// nodes with up to kLeafMax triangles per leaf -> leaf-order triangle copies).  World-space positions and normals are produced with the reference's own expressions
 // (matVecMul, GPURaytracer.cu:728-743; normals through the transposed inverse, :463-469) so the
 // render kernel tests exactly the triangles the reference would.
 #include "rt_device.h"
