@@ -118,7 +118,7 @@ constexpr uint32_t kWfDanger = 0x80000000u; // hitG flag: the pixel must be re-r
 struct WfBufs {
     // per level, indexed by queue position (stripe, offset), ping-pong over levels like the queue:
     // a level's shade launch reads its entries front to back and writes the survivors' next to each other
-    float4* rayO;        // [2][kWfStripes][subCap] origin, maxDistance
+    float4* rayO;        // [2][kWfStripes][subCap] origin, maxDistance (levels >= 1; level 0 = the camera's, wf_ray_origin)
     float4* rayD;        // [2][kWfStripes][subCap] direction, RNG state
     float4* accO;        // [2][kWfStripes][subCap] outgoing light, checksum bits
     float4* accB;        // [2][kWfStripes][subCap] beta accumulation

@@ -768,6 +768,13 @@ __device__ __forceinline__ size_t wf_hit_pos(const WfBufs& w, uint32_t stripe, u
 {
     return (size_t)stripe * (size_t)w.subCap + off;
 }
+// origin + maxDistance of a level's ray: the camera rays all start at the camera with the renderer's
+// maxDistance (setup_ray), so level 0 keeps no copy (16 bytes per sample less to write, and to read twice)
+__device__ __forceinline__ float4 wf_ray_origin(const RenderArgs& a, const WfBufs& w, int level, size_t p)
+{
+    if (level == 0) return make_float4(a.camOrigin[0], a.camOrigin[1], a.camOrigin[2], a.maxDistance);
+    return w.rayO[p];
+}
 // finished-sample results are stored sample-major inside each 64-pixel tile, so that wf_resolve's
 // lanes (one pixel each) read consecutive addresses
 __device__ __forceinline__ size_t wf_out_index(uint32_t pix, uint32_t sidx, uint32_t spp)
@@ -804,7 +811,6 @@ __global__ __launch_bounds__(256) void wf_gen_kernel(const RenderArgs a, const W
             uint32_t seed = sample_seed(a, x, y, sidx);
             const Ray ray = setup_ray(a, x, y, seed);
             if (a.bounceCount > 0) {
-                w.rayO[wf_pos(w, 0, stripe, off)] = make_float4(ray.ox, ray.oy, ray.oz, ray.maxDist);
                 w.rayD[wf_pos(w, 0, stripe, off)] = make_float4(ray.dx, ray.dy, ray.dz, __uint_as_float(seed));
                 entry = i; // outgoing light 0, beta 1, checksum 0: wf_shade(0) supplies them
             } else { // the bounce loop does not run: radiance 0 (:172)
@@ -890,7 +896,7 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
             const size_t p = wf_pos(w, level, stripe, off + (uint32_t)lane);
             const bool in = (uint32_t)lane < n;
             nSlot = in ? w.queue[p] : kWfHole;
-            if (in) { nO = w.rayO[p]; nD = w.rayD[p]; }
+            if (in) { nO = wf_ray_origin(a, w, level, p); nD = w.rayD[p]; }
             nOff = (uint32_t)wf_hit_pos(w, stripe, off + (uint32_t)lane);
             issue_claim();
         }
@@ -1035,7 +1041,7 @@ __global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const R
         const bool active = slot != kWfHole;
         Ray ray; ray.ox = ray.oy = ray.oz = 0.0f; ray.dx = 1.0f; ray.dy = ray.dz = 0.0f; ray.maxDist = -1.0f;
         if (active) {
-            const float4 o = w.rayO[p], d = w.rayD[p];
+            const float4 o = wf_ray_origin(a, w, level, p), d = w.rayD[p];
             ray.ox = o.x; ray.oy = o.y; ray.oz = o.z; ray.maxDist = o.w; ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
         }
         Trav T; trav_init(T, a.scene, ray); // a lane without a ray has bound -1: it enters no box and accepts no hit
@@ -1174,7 +1180,7 @@ __global__ __launch_bounds__(256) void wf_exact_kernel(const RenderArgs a, const
         for (uint32_t step = kWfStripes / 2; step > 0; step >>= 1)
             if (listBase[ls + step] <= i) ls += step;
         const uint32_t hp = w.exactList[(size_t)ls * w.subCap + (i - listBase[ls])];
-        const float4 o = w.rayO[half + hp], d = w.rayD[half + hp];
+        const float4 o = wf_ray_origin(a, w, level, half + hp), d = w.rayD[half + hp];
         Ray ray; ray.ox = o.x; ray.oy = o.y; ray.oz = o.z; ray.maxDist = o.w; ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
         Hit h;
         if (!trace_band_table(a.scene, ray, w.hitA[hp].x, stack, st.bvh, h)) {
@@ -1189,7 +1195,10 @@ __global__ __launch_bounds__(256) void wf_exact_kernel(const RenderArgs a, const
 }
 
 // material evaluation, BRDF and bounce ray of one level (:172-242): one lane per live path
-__global__ __launch_bounds__(256) void wf_shade_kernel(const RenderArgs a, const WfBufs w, const int level)
+#ifndef RT_SHADE_OCC
+#define RT_SHADE_OCC 4
+#endif
+__global__ __launch_bounds__(256, RT_SHADE_OCC) void wf_shade_kernel(const RenderArgs a, const WfBufs w, const int level)
 {
     __shared__ uint32_t wgCnt[8];
     LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
@@ -1197,9 +1206,10 @@ __global__ __launch_bounds__(256) void wf_shade_kernel(const RenderArgs a, const
     const uint32_t piecesPerStripe = (w.subCap + 255u) / 256u;
     const uint32_t total = piecesPerStripe * kWfStripes;
     for (uint32_t piece = blockIdx.x; piece < total; piece += gridDim.x) {
-        const uint32_t stripe = piece % kWfStripes, off = (piece / kWfStripes) * 256u + threadIdx.x;
+        const uint32_t stripe = piece % kWfStripes, pieceBase = (piece / kWfStripes) * 256u;
+        const uint32_t off = pieceBase + threadIdx.x;
         const uint32_t cnt = *wf_count(w, level, (int)stripe);
-        if ((piece / kWfStripes) * 256u >= cnt) continue; // uniform per workgroup
+        if (pieceBase >= cnt) continue; // uniform per workgroup
         const size_t pin = wf_pos(w, level, stripe, off), ph = wf_hit_pos(w, stripe, off);
         const uint32_t slot = off < cnt ? w.queue[pin] : kWfHole;
         bool more = false;
@@ -1209,7 +1219,7 @@ __global__ __launch_bounds__(256) void wf_shade_kernel(const RenderArgs a, const
         if (slot != kWfHole) {
             const uint32_t spp = a.sampleCount;
             const uint32_t pix = slot / spp, sidx = slot - pix * spp;
-            const float4 o = w.rayO[pin], d = w.rayD[pin], hA = w.hitA[ph];
+            const float4 o = wf_ray_origin(a, w, level, pin), d = w.rayD[pin], hA = w.hitA[ph];
             const float4 aO = level == 0 ? make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u)) : w.accO[pin];
             const float4 aB = level == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : w.accB[pin];
             const uint32_t hG = w.hitG[ph];
