@@ -198,6 +198,18 @@ __global__ void detmath_kernel(int op, const float* __restrict__ in, int n, floa
     case 3: r = rtd::pow_f(x, 5.0f); break;
     case 4: r = rtd::pow_f(x, 1000.0f); break;
     case 5: r = rtd::rsqrt_f(x); break;
+    case 7: r = rtd::byte_unorm(__float_as_uint(x)); break;
+    case 8: { // exhaustive check of u32_unorm: the input is the top 16 bits of v; the result is the number of mismatches
+        const uint32_t hi = __float_as_uint(x) << 16;
+        uint32_t bad = 0;
+        for (uint32_t lo = 0; lo < 65536u; lo++) {
+            const uint32_t v = hi | lo;
+            const float want = (float)((double)v / 4294967295.0);
+            bad += __float_as_uint(rtd::u32_unorm(v)) != __float_as_uint(want) ? 1u : 0u;
+        }
+        r = (float)bad;
+        break;
+    }
     default: {
         uint32_t seed = __float_as_uint(x);
         seed = seed * 747796405u + 2891336453u;
@@ -790,7 +802,7 @@ int rt_event_elapsed_ms(rt_ctx* c, int a, int b, float* ms)
 int rt_detmath_eval(rt_ctx* c, int op, const float* in, int32_t n, float* out)
 {
     RT_BIND(c);
-    if (op < 0 || op > 6 || n < 0 || (n > 0 && (!in || !out))) return fail(c, RT_ERR_INVALID, "bad detmath request");
+    if (op < 0 || op > 8 || n < 0 || (n > 0 && (!in || !out))) return fail(c, RT_ERR_INVALID, "bad detmath request");
     if (n == 0) return RT_OK;
     float *di = nullptr, *dout = nullptr;
     RT_CHECK(c, hipMalloc((void**)&di, 4 * (size_t)n));

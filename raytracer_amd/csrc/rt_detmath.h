@@ -154,6 +154,29 @@ __device__ __forceinline__ float pow_f(float x, float y)
     return (float)exp_core(p);
 }
 
+// b / 255.0f, correctly rounded, for a byte b -- the texel conversion (Material.cu:199-206 divides on the host;
+// here the texels stay RGBA8 and every tap converts).  q = b * fl(1/255) is within an ulp; one residual step
+// r = fma(-255, q, b), q + r * fl(1/255) lands on the correctly rounded quotient for all 256 bytes (checked
+// exhaustively: tests/test_parity_gpu.py::test_detmath_matches_oracle_bit_for_bit and, in exact rational
+// arithmetic, tests/test_oracle.py).  3 instructions instead of the ~10 of an IEEE division, 16 per texture tap set.
+__device__ __forceinline__ float byte_unorm(uint32_t b)
+{
+    const float p = (float)b, c = 0x1.010102p-8f;
+    const float q = p * c;
+    const float r = __builtin_fmaf(-255.0f, q, p);
+    return __builtin_fmaf(r, c, q);
+}
+
+// (float)(v / 4294967295.0), the RNG's last step (:824), without the binary64 division: the product with
+// fl64(1 / 4294967295) is within 2^-52 of the quotient, and no quotient v / (2^32 - 1) lies that close to a
+// binary32 rounding boundary (v * 2^-32 * (1 + 2^-32 + ...): past the 24 kept bits, an exact-looking half is
+// always followed by the 2^-32 term).  Checked against the division for all 2^32 values of v on the GPU
+// (tests/test_parity_gpu.py::test_detmath_matches_oracle_bit_for_bit).
+__device__ __forceinline__ float u32_unorm(uint32_t v)
+{
+    return (float)((double)v * (1.0 / 4294967295.0));
+}
+
 // CUDA max()/min() on floats drop a NaN operand (fmaxf/fminf); pinned select form
 __device__ __forceinline__ float fmax_f(float a, float b)
 {

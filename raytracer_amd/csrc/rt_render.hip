@@ -57,10 +57,7 @@ __device__ __forceinline__ float random_value(uint32_t& seed)
     seed = seed * 747796405u + 2891336453u;
     uint32_t r = ((seed >> ((seed >> 28) + 4u)) ^ seed) * 277803737u;
     r = (r >> 22) ^ r;
-#ifdef RT_ABLATE_RNG
-    return (float)r * 2.3283064e-10f; // timing-only build
-#endif
-    return (float)((double)r / 4294967295.0);
+    return rtd::u32_unorm(r); // = (float)(r / 4294967295.0)
 }
 // :827-833
 __device__ __forceinline__ float random_normal(uint32_t& seed)
@@ -106,10 +103,7 @@ __device__ __forceinline__ V4 bilerp(const V4& t00, const V4& t10, const V4& t01
 __device__ __forceinline__ V4 texel8(const DevTexture& t, int x, int y)
 {
     const uchar4 p = t.data[(size_t)y * (size_t)t.w + (size_t)x];
-#ifdef RT_ABLATE_TEXDIV
-    return mk4((float)p.x * 0.003921569f, (float)p.y * 0.003921569f, (float)p.z * 0.003921569f, (float)p.w * 0.003921569f); // timing-only build
-#endif
-    return mk4((float)p.x / 255.0f, (float)p.y / 255.0f, (float)p.z / 255.0f, (float)p.w / 255.0f);
+    return mk4(rtd::byte_unorm(p.x), rtd::byte_unorm(p.y), rtd::byte_unorm(p.z), rtd::byte_unorm(p.w)); // = p / 255.0f
 }
 // Material.cu:224-228: normalized coordinates, linear, clamp
 __device__ __forceinline__ V4 tex2d_norm(const DevTexture& t, float u, float v)

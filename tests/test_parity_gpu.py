@@ -289,6 +289,11 @@ def test_detmath_matches_oracle_bit_for_bit(ctx):
         got = ctx.detmath(op, x)
         exp = np.array([f(float(v)) for v in x], np.float32)
         assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), op
+    # the two division-free conversions against the divisions they stand for: every byte, every 32-bit value
+    b = np.arange(256, dtype=np.uint32)
+    assert np.array_equal(ctx.detmath(7, b.view(np.float32)), (b.astype(np.float32) / np.float32(255.0)))
+    hi = np.arange(65536, dtype=np.uint32)
+    assert ctx.detmath(8, hi.view(np.float32)).sum() == 0.0
     seeds = rng.integers(0, 2**32, 50000, dtype=np.uint64).astype(np.uint32)
     got = ctx.detmath(6, seeds.view(np.float32))
     import ctypes as C
