@@ -1205,6 +1205,9 @@ __global__ __launch_bounds__(256, RT_SHADE_OCC) void wf_shade_kernel(const Rende
         const uint32_t cnt = *wf_count(w, level, (int)stripe);
         if (pieceBase >= cnt) continue; // uniform per workgroup
         const size_t pin = wf_pos(w, level, stripe, off), ph = wf_hit_pos(w, stripe, off);
+        // the hit word gates the longest chain of dependent fetches (triangle -> object, material -> texture -> texels):
+        // it goes out first, so that the chain starts while the rest of the path state is still arriving
+        const uint32_t hG0 = off < cnt ? w.hitG[ph] : kWfMiss;
         const uint32_t slot = off < cnt ? w.queue[pin] : kWfHole;
         bool more = false;
         Ray nray; nray.ox = nray.oy = nray.oz = nray.dx = nray.dy = nray.dz = nray.maxDist = 0.0f;
@@ -1216,7 +1219,7 @@ __global__ __launch_bounds__(256, RT_SHADE_OCC) void wf_shade_kernel(const Rende
             const float4 o = wf_ray_origin(a, w, level, pin), d = w.rayD[pin], hA = w.hitA[ph];
             const float4 aO = level == 0 ? make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u)) : w.accO[pin];
             const float4 aB = level == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : w.accB[pin];
-            const uint32_t hG = w.hitG[ph];
+            const uint32_t hG = hG0;
             Ray ray; ray.ox = o.x; ray.oy = o.y; ray.oz = o.z; ray.maxDist = o.w; ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
             uint32_t seed = __float_as_uint(d.w), checksum = __float_as_uint(aO.w);
             PathAcc acc; acc.ox = aO.x; acc.oy = aO.y; acc.oz = aO.z; acc.bx = aB.x; acc.by = aB.y; acc.bz = aB.z;

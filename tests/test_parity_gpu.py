@@ -284,6 +284,8 @@ def test_detmath_matches_oracle_bit_for_bit(ctx):
              (1, (u * 2000 - 1000).astype(np.float32), L.or_cosf),
              (2, (-u * 110).astype(np.float32), L.or_expf), (2, (u * 95).astype(np.float32), L.or_expf),
              (3, u, lambda x: L.or_powf(x, 5.0)), (4, (1 - u * np.float32(0.03)).astype(np.float32), lambda x: L.or_powf(x, 1000.0)),
+             (4, u[:50000], lambda x: L.or_powf(x, 1000.0)),                                         # the whole unit interval: almost all of it underflows to 0
+             (4, np.nextafter(np.float32(0.875), np.float32([0, 1, 0.875])), lambda x: L.or_powf(x, 1000.0)),
              (5, (u * 100).astype(np.float32), L.or_rsqrtf)]
     for op, x, f in cases:
         got = ctx.detmath(op, x)
