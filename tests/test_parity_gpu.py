@@ -532,3 +532,28 @@ def test_axis_parallel_rays(ctx):
     st = RenderSettings(bounceCount=3, sampleCount=2, antiAliasingEnabled=False)
     _, _, stats = compare_modes(ctx, flat, cam, st, modes=(0, 2))
     assert stats.node_visits < 150 * stats.rays, "box tests per ray out of proportion: axis-parallel rays are visiting whole planes"
+
+
+def test_non_finite_vertices(ctx):
+    """A mesh with NaN and infinite coordinates among ordinary triangles: the reference's tests simply never
+    accept such a triangle; the build has to terminate on boxes without a finite area (both builders) and the
+    traversal must still find every finite triangle."""
+    rng = np.random.default_rng(11)
+    n = 60
+    v = rng.uniform(-1.5, 1.5, (n * 3, 3)).astype(np.float32)
+    v[7, 1] = np.nan; v[40, 0] = np.inf; v[41, 2] = -np.inf; v[100, :] = np.nan; v[150, 0] = np.float32(3e38)
+    mesh = Mesh(v.reshape(-1), np.arange(n * 3, dtype=np.int32), rng.random(n * 6).astype(np.float32), None)
+    o = MeshObject([(mesh, 0)], [Material("m", (0.6, 0.6, 0.3, 1.0), 0.5, 0.2)])
+    o.compositeMinBounds = np.array([-2, -2, -2], np.float32); o.compositeMaxBounds = np.array([2, 2, 2], np.float32)
+    sc = Scene(); sc.addToScene("soup", o)
+    c = Cube(); c.setPosition((0.0, -2.2, 0.0)); c.setMaterial(Material("c", (0.3, 0.5, 0.7, 1.0), 0.4, 0.0)); sc.addToScene("cube", c)
+    cam = Camera((0.3, 0.4, 6.0)); cam.setWidth(80); cam.setHeight(60); cam.calcRays()
+    st = RenderSettings(bounceCount=3, sampleCount=2)
+    flat = sc.flatten()
+    for builder in (0, 1):
+        ctx.set_option(capi.OPT_BUILDER, builder)
+        try:
+            _, rid, _ = compare_modes(ctx, flat, cam, st)
+        finally:
+            ctx.set_option(capi.OPT_BUILDER, 0)
+    assert (rid[..., 0] == 0).any() and (rid[..., 0] == 1).any()
