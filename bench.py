@@ -111,6 +111,10 @@ def main():
     fb_t = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     acc_t = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     fb = ctx.framebuffer_wrap(fb_t.data_ptr(), W, H)
+    # frames mode: two buffers, so that the RCCL reduce of one frame runs while the next one renders
+    fb_t2 = torch.zeros((H, W, 4), dtype=torch.float32, device=dev) if args.mode == "frames" else None
+    fb2 = ctx.framebuffer_wrap(fb_t2.data_ptr(), W, H) if fb_t2 is not None else None
+    fa = multigpu.FrameAccumulator(dist, world, rank, [fb_t, fb_t2], acc_t) if args.mode == "frames" else None
 
     if args.mode == "tiles":
         rects = multigpu.band_rects(W, H, rank, world)
@@ -118,22 +122,22 @@ def main():
         rects = [(0, 0, W, H)]
 
     def step(frame_base):
+        st.progressiveFrameCount = 0
         if args.mode == "frames":
             st.frameCount = frame_base * world + rank
+            b = fa.acquire(frame_base)
+            ctx.render(cam, st, (fb, fb2)[b], rects[0])
+            fa.submit(b)
         else:
             st.frameCount = frame_base
-        st.progressiveFrameCount = 0
-        for r in rects:
-            ctx.render(cam, st, fb, r)
-        if world > 1:
-            if args.mode == "frames":
-                dist.reduce(fb_t, dst=0, op=dist.ReduceOp.SUM)
-            else:
+            for r in rects:
+                ctx.render(cam, st, fb, r)
+            if world > 1:
                 multigpu.composite_tiles(dist, fb_t, W, H, rank, world)
-        if args.mode == "frames":
-            acc_t.add_(fb_t)
 
     def barrier():
+        if fa is not None:
+            fa.drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -147,6 +151,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    if fa is not None:
+        fa.drain()
     ctx.event_record(1)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -225,7 +231,7 @@ def main():
                          "valu": {"achieved": achieved_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                   "frac": achieved_tf / FP32_PEAK_TFLOPS, "flop_per_ray": alg_flops / max(1, rays_local)}},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU leg runs at N = 1 only
             from oracle import oracle_py as orc
             # bounded sample: the oracle is brute force (every ray tests every triangle of every object it does
             # not cull), so the crop shrinks with the scene to keep the CPU leg around 10-30 s

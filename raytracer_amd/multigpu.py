@@ -59,3 +59,46 @@ def reduce_frames(dist, local_sum, world, dst=0):
     if world > 1:
         dist.reduce(local_sum, dst=dst, op=dist.ReduceOp.SUM)
     return local_sum
+
+
+class FrameAccumulator:
+    """frames partitioning with the exchange hidden: frame i is rendered into buffer i % 2 and its
+    reduce(SUM) to `dst` is launched asynchronously, so it runs while the next frame renders into the
+    other buffer.  Before a buffer is rendered into again its reduce is waited for (with RCCL that is a
+    stream dependency, not a host wait) and, on `dst`, the reduced frame is added to `acc`.
+
+        b = fa.acquire(i)        # buffer index for frame i, free to be written
+        render(buffers[b])       # enqueue the frame
+        fa.submit(b)             # launch its reduce
+        ...
+        fa.drain()               # all reduces finished, acc complete on dst
+    """
+
+    def __init__(self, dist, world, rank, buffers, acc, dst=0):
+        assert len(buffers) == 2
+        self.dist, self.world, self.rank, self.buffers, self.acc, self.dst = dist, world, rank, buffers, acc, dst
+        self.pending = [None, None]
+        self.dirty = [False, False]
+
+    def _finish(self, b):
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+            self.pending[b] = None
+        if self.dirty[b]:
+            if self.rank == self.dst:
+                self.acc.add_(self.buffers[b])
+            self.dirty[b] = False
+
+    def acquire(self, i):
+        b = i & 1
+        self._finish(b)
+        return b
+
+    def submit(self, b):
+        if self.world > 1:
+            self.pending[b] = self.dist.reduce(self.buffers[b], dst=self.dst, op=self.dist.ReduceOp.SUM, async_op=True)
+        self.dirty[b] = True
+
+    def drain(self):
+        self._finish(0)
+        self._finish(1)

@@ -155,8 +155,26 @@ if rank == 0:
         st.frameCount = f
         serial += orc.render(flat, cam, st, threads=1)[0]
     assert np.abs(local.numpy() / 6 - serial / 6).max() < 1e-6
+# the same split through the double-buffered accumulator bench.py uses (reduce of frame i behind the render of i+1)
+bufs = [torch.zeros((48, 64, 4)), torch.zeros((48, 64, 4))]
+acc = torch.zeros((48, 64, 4))
+fa = multigpu.FrameAccumulator(dist, world, rank, bufs, acc)
+for step in range(3):
+    b = fa.acquire(step)
+    st.frameCount = step * world + rank
+    bufs[b].copy_(torch.from_numpy(orc.render(flat, cam, st, threads=1)[0]))
+    fa.submit(b)
+fa.drain()
+if rank == 0:
+    serial = np.zeros((48, 64, 4), np.float64)
+    for f in range(3 * world):
+        st.frameCount = f
+        serial += orc.render(flat, cam, st, threads=1)[0]
+    assert np.abs(acc.numpy() / (3 * world) - serial / (3 * world)).max() < 1e-6
+else:
+    assert float(acc.abs().max()) == 0.0
 dist.barrier(); dist.destroy_process_group()
-print("rank", rank, "ok")
+sys.stdout.write("rank %d ok\n" % rank); sys.stdout.flush()  # one write: the two ranks finish together
 '''
 
 
