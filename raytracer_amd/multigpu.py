@@ -36,21 +36,30 @@ def frame_indices(first: int, count: int, rank: int, world: int) -> List[int]:
 
 
 def composite_tiles(dist, local_fb, width, height, rank, world, band_rows: int = BAND_ROWS):
-    """all_gather of the full-size framebuffers and selection of each band from its owner.
-    `local_fb` is a torch tensor [H, W, 4]; rows not owned by this rank are ignored.
-    (Equal-sized buffers keep the collective a plain all_gather; the GPU bench gathers only the
-    owned bands.)"""
+    """Composite of one frame rendered as interleaved row bands: every rank packs the bands it owns into one
+    contiguous tensor, one all_gather moves them (1/world of a frame per rank instead of a whole frame), and
+    each rank unpacks every owner's bands into place.  `local_fb` is a torch tensor [H, W, 4]; rows this rank
+    does not own are ignored on input and filled on output.  Ranks that own one band fewer (or a short last
+    band) pad their packet with zeros so that the collective stays a plain equal-sized all_gather."""
     import torch
 
     if world == 1:
         return local_fb
-    parts = [torch.empty_like(local_fb) for _ in range(world)]
-    dist.all_gather(parts, local_fb)
-    out = torch.empty_like(local_fb)
     nb = (height + band_rows - 1) // band_rows
-    for b in range(nb):
+    per_rank = (nb + world - 1) // world                      # bands in a packet
+    def owned(r):
+        return list(range(r, nb, world))
+    packet = torch.zeros((per_rank * band_rows, width, 4), dtype=local_fb.dtype, device=local_fb.device)
+    for k, b in enumerate(owned(rank)):
         y0, y1 = b * band_rows, min(height, (b + 1) * band_rows)
-        out[y0:y1] = parts[b % world][y0:y1]
+        packet[k * band_rows:k * band_rows + (y1 - y0)] = local_fb[y0:y1]
+    parts = [torch.empty_like(packet) for _ in range(world)]
+    dist.all_gather(parts, packet)
+    out = torch.empty_like(local_fb)
+    for r in range(world):
+        for k, b in enumerate(owned(r)):
+            y0, y1 = b * band_rows, min(height, (b + 1) * band_rows)
+            out[y0:y1] = parts[r][k * band_rows:k * band_rows + (y1 - y0)]
     return out
 
 

@@ -141,6 +141,12 @@ for r in multigpu.band_rects(64, 48, rank, world):
     fb[r[1]:r[3]] = part[r[1]:r[3]]
 comp = multigpu.composite_tiles(dist, torch.from_numpy(fb), 64, 48, rank, world).numpy()
 assert np.array_equal(comp, full), "tile composite differs from the single-rank frame"
+# ragged case: 8-row bands over 44 rows = 6 bands, the last one short, packets padded
+fb2 = np.zeros((48, 64, 4), np.float32)
+for r in multigpu.band_rects(64, 44, rank, world, band_rows=8):
+    fb2[r[1]:r[3]] = full[r[1]:r[3]]
+comp2 = multigpu.composite_tiles(dist, torch.from_numpy(fb2[:44].copy()), 64, 44, rank, world, band_rows=8).numpy()
+assert np.array_equal(comp2, full[:44]), "ragged tile composite differs"
 # frames: progressive split + reduce == serial sum within 1e-6
 frames = list(range(0, 6))
 local = torch.zeros((48, 64, 4))
