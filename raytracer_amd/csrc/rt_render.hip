@@ -1231,6 +1231,9 @@ __global__ __launch_bounds__(256, RT_SHADE_OCC) void wf_shade_kernel(const Rende
             if (h.gid != kNoHit) { cullObj = a.scene.triRef[h.gid].obj; ray.maxDist = h.t; }
             uint32_t primary[3] = { kNoHit, kNoHit, kNoHit };
             more = shade_segment(a, h, ray, seed, sidx, level, acc, st, checksum, primary, cullObj, m0, &danger);
+#ifdef RT_DEBUG_FLAGS
+            if (danger) printf("flag: level %d pix %u overflow %d gid %u\n", level, pix, (int)((hG & kWfDanger) != 0u), h.gid);
+#endif
             if (danger) w.pixFlag[pix] = 1u;
             if (level == 0 && sidx == 0 && a.ids) {
                 int x, y;
