@@ -439,7 +439,7 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
 // uneven the rays; in the reference (and in the tile kernel below) a wave pays for its longest
 // path and its longest ray while the other lanes sit idle.
 #ifndef RT_KEEP_NUM
-#define RT_KEEP_NUM 2
+#define RT_KEEP_NUM 3
 #endif
 constexpr int kKeepNum = RT_KEEP_NUM, kKeepDen = 8;
 
