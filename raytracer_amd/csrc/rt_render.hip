@@ -1421,7 +1421,10 @@ void launch_render_wf(const RenderArgs& a, const WfLanes& L, int numCUs, hipStre
         uint32_t gridT = (uint32_t)numCUs * RT_WF_OCC;
         const uint32_t needT = (nPieces + 3u) / 4u; // never more waves than 64-entry grabs
         if (gridT > needT) gridT = needT;
-        uint32_t gridS = (uint32_t)numCUs * 8u;
+#ifndef RT_SHADE_GRID
+#define RT_SHADE_GRID 8u
+#endif
+        uint32_t gridS = (uint32_t)numCUs * RT_SHADE_GRID;
         if (gridS > nPieces) gridS = nPieces;
         for (int level = 0; level < levels; level++) {
             if (level == 0) {
