@@ -93,6 +93,9 @@ public:
     ~Device() { rt_ctx_destroy(ctx_); }
     Device(const Device&) = delete;
     rt_ctx* ctx() const { return ctx_; }
+    // library options (include/rt_api.h, enum rt_option): e.g. setOption(RT_OPT_BUILDER, 1) for a scene that is
+    // re-committed every frame (the reference's Scene::getGPUObjectDataVector pattern)
+    void setOption(int option, int value) const { check(rt_set_option(ctx_, option, value)); }
     void check(int rc) const { if (rc != RT_OK) throw std::runtime_error(std::string("librt_amd: ") + rt_last_error(ctx_)); }
 private:
     rt_ctx* ctx_ = nullptr;
