@@ -48,6 +48,12 @@ def test_config1(ctx, mode, spp, depth):
     img, ids, stats = render_gpu(ctx, flat, cam, st, mode)
     check(ref, rid, nq, img, ids, stats)
     assert np.array_equal(img, ref), "radiance is expected to match bit for bit"
+    if mode == 0 and depth > 0:
+        # the camera rays went through the packet kernel: one node fetch serves up to 64 box tests
+        assert 0 < stats.packet_node_tests <= stats.node_visits
+        assert stats.packet_node_fetches <= stats.packet_node_tests <= 64 * stats.packet_node_fetches
+    elif mode != 0:
+        assert stats.packet_node_tests == 0 and stats.packet_node_fetches == 0
 
 
 import os
