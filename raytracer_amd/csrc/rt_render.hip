@@ -273,12 +273,14 @@ __device__ __forceinline__ bool shade_segment(const RenderArgs& a, const Hit& h,
     }
     uint32_t ho, hm, ht;
     st.hits++;
+#ifndef RT_ABLATE_CULL
     if (cullObj != kNoHit) {
         const ObjCull o = load_obj(a.scene.objects + cullObj);
         float tmin, bfar;
         object_slab(ray, o, tmin, bfar);
         if (!object_cull_pass(tmin, bfar, cullMax)) *cullFail = true;
     }
+#endif
     const Surface sf = shade_surface(a.scene, h, ho, hm, ht);
     checksum += seg_hash(ho, hm, ht, sample, (uint32_t)i);
     if (i == 0 && sample == 0) { primary[0] = ho; primary[1] = hm; primary[2] = ht; }
