@@ -162,13 +162,8 @@ class Context:
             self.check(L.rt_texture_create(h, t.ctypes.data, t.shape[1], t.shape[0], C.byref(out)))
             ids["tex"].append(out.value)
 
-        def tx(i):
-            return -1 if i < 0 else ids["tex"][i]
-
         for m in flat.materials:
-            d = MaterialDesc((C.c_float * 4)(*m["albedo"]), float(m["roughness"]), float(m["metal"]),
-                             (C.c_float * 3)(*m["emissionColor"]), float(m["emissionStrength"]),
-                             tx(m["texNormal"]), tx(m["texAlbedo"]), tx(m["texRoughness"]), tx(m["texMetal"]))
+            d = self.material_desc(m, ids["tex"])
             self.check(L.rt_material_create(h, C.byref(d), C.byref(out)))
             ids["mat"].append(out.value)
         models, invs = [], []
@@ -186,6 +181,20 @@ class Context:
         self._scene_handles = ids
         self.commit(ids["obj"], models, invs)
         return ids
+
+    @staticmethod
+    def material_desc(m: dict, tex_handles) -> "MaterialDesc":
+        """rt_material_desc of a FlatScene material; texture indices become handles."""
+        def tx(i):
+            return -1 if i < 0 else tex_handles[i]
+        return MaterialDesc((C.c_float * 4)(*m["albedo"]), float(m["roughness"]), float(m["metal"]),
+                            (C.c_float * 3)(*m["emissionColor"]), float(m["emissionStrength"]),
+                            tx(m["texNormal"]), tx(m["texAlbedo"]), tx(m["texRoughness"]), tx(m["texMetal"]))
+
+    def update_material(self, handle, m: dict, tex_handles):
+        """Material::sendToGPU on a live material (Material.hpp:155-159): patches the committed scene in place."""
+        d = self.material_desc(m, tex_handles)
+        self.check(self.L.rt_material_update(self.h, handle, C.byref(d)))
 
     def commit(self, object_ids, models, invs):
         n = len(object_ids)
@@ -297,6 +306,9 @@ class GPURaytracer:
         self.ctx = ctx
         self.st = RenderSettings()
         self._scene = None
+        self._key = None
+        self._mat_keys = []
+        self._keep = None
 
     def setBounceCount(self, n): self.st.bounceCount = int(n)
     def setMaxDistance(self, d): self.st.maxDistance = float(d)
@@ -318,11 +330,12 @@ class GPURaytracer:
         self.st.lightDirection = hostmath.sky_direction(pitch, yaw)
 
     def raytrace(self, scene: Scene, camera: Camera, fb, rect=None):
-        """GPURaytracer::raytrace (GPURaytracer.cu:24-74).  The scene is flattened and committed
-        on every call, as the reference rebuilds its instance table every frame (Scene.cpp:3-29);
-        pass the same Scene object with `static=True` semantics via commit_scene() to skip it."""
-        if self._scene is not scene:
-            self.commit_scene(scene)
+        """GPURaytracer::raytrace (GPURaytracer.cu:24-74).  The reference rebuilds its instance table from
+        the live objects on every call (Scene.cpp:3-29), so edits to the Scene between two calls show in the
+        next frame.  Here the scene is flattened on every call too; when only transforms and material values
+        changed, the meshes and textures already on the device are kept and the scene is re-committed on
+        their handles (rt_scene_commit + rt_material_update), otherwise everything is uploaded again."""
+        self.commit_scene(scene)
         camera.update()
         self.ctx.set_camera_rays(camera.preTransformRays)
         self.ctx.render(camera, self.st, fb, rect)
@@ -333,6 +346,34 @@ class GPURaytracer:
         else:
             self.st.progressiveFrameCount = 0
 
+    @staticmethod
+    def _structure(flat: FlatScene):
+        """What has to be equal for the device meshes / textures / objects to be reusable."""
+        return (tuple(id(m) for m in flat.meshes), tuple(id(t) for t in flat.textures), len(flat.materials),
+                tuple((tuple(o["meshIds"]), tuple(o["materialIndices"]), tuple(o["materialIds"]),
+                       o["bmin"].tobytes(), o["bmax"].tobytes()) for o in flat.objects))
+
+    @staticmethod
+    def _material_key(m: dict):
+        return (np.asarray(m["albedo"], np.float32).tobytes(), float(m["roughness"]), float(m["metal"]),
+                np.asarray(m["emissionColor"], np.float32).tobytes(), float(m["emissionStrength"]),
+                m["texNormal"], m["texAlbedo"], m["texRoughness"], m["texMetal"])
+
     def commit_scene(self, scene: Scene):
-        self.ctx.upload_scene(scene.flatten())
+        flat = scene.flatten()
+        key = self._structure(flat)
+        ids = self.ctx._scene_handles
+        if self._scene is scene and ids and key == self._key:
+            for k, m in enumerate(flat.materials):
+                mk = self._material_key(m)
+                if mk != self._mat_keys[k]:
+                    self.ctx.update_material(ids["mat"][k], m, ids["tex"])
+                    self._mat_keys[k] = mk
+            self.ctx.commit(ids["obj"], [np.asarray(o["model"], np.float32) for o in flat.objects],
+                            [np.asarray(o["invModel"], np.float32) for o in flat.objects])
+        else:
+            self.ctx.upload_scene(flat)
+            self._key = key
+            self._mat_keys = [self._material_key(m) for m in flat.materials]
+            self._keep = flat      # the ids in the key stay unique while these arrays are alive
         self._scene = scene

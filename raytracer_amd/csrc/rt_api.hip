@@ -51,6 +51,7 @@ struct rt_ctx {
     bool committed = false;
     rt::ObjCull* dObjects = nullptr; uint32_t nObjects = 0;
     rt::DevMaterial* dMaterials = nullptr; size_t capMaterials = 0;
+    std::vector<rt::DevMaterial> hMaterials;   // host copy of dMaterials: which textures the committed scene can reach
     rt::DevTexture* dTextures = nullptr; size_t capTextures = 0;
 
     float4* dRays = nullptr; int32_t raysW = 0, raysH = 0;
@@ -64,7 +65,8 @@ struct rt_ctx {
     int optWfLanes = 0;                       // 0 = by the number of chunks
     int optBuilder = 0;                       // 0 = PLOC, 1 = radix tree
     size_t optWfChunk = kWfChunkDefault;     // samples in flight per chunk of the wavefront pipeline
-    rt::WfLanes wf; size_t wfCapSlots = 0; int wfLevels = 0; int wfLanes = 0; // its lanes and their workspace (wf.bufs[0] owns the allocations)
+    void* wfArena = nullptr;                  // one allocation, carved per lane by wf_carve
+    rt::WfLanes wf; size_t wfCapSlots = 0; int wfLevels = 0; int wfLanes = 0; // its lanes and their workspace
     int optCounters = 0;
     int optAccumulate = 0;
     int numCUs = 256;
@@ -123,16 +125,61 @@ int check_material_desc(rt_ctx* c, const rt_material_desc* d)
     return RT_OK;
 }
 
+// device table of the live textures (index = handle); the stream must be idle
+int upload_texture_table(rt_ctx* c)
+{
+    std::vector<rt::DevTexture> texs(c->textures.size() ? c->textures.size() : 1);
+    memset(texs.data(), 0, sizeof(rt::DevTexture) * texs.size());
+    for (size_t i = 0; i < c->textures.size(); i++)
+        if (c->textures[i].live) { texs[i].data = c->textures[i].data; texs[i].w = c->textures[i].w; texs[i].h = c->textures[i].h; }
+    if (texs.size() > c->capTextures) {
+        hipFree(c->dTextures); c->dTextures = nullptr; c->capTextures = 0;
+        RT_CHECK(c, hipMalloc((void**)&c->dTextures, sizeof(rt::DevTexture) * texs.size()));
+        c->capTextures = texs.size();
+    }
+    RT_CHECK(c, hipMemcpy(c->dTextures, texs.data(), sizeof(rt::DevTexture) * texs.size(), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+// Lays one lane's wavefront workspace out in [base, base + return value): ~185 bytes per sample in flight
+// (path state of both ping-pong halves 128, hit 20, result 17, queue 8, exact list 4, pixel flag + redo list 8).
+// base == nullptr: sizing only.  Every array starts on a 256-byte boundary.
+size_t wf_carve(uint8_t* base, size_t slots, int levels, rt::WfBufs& w)
+{
+    w = rt::WfBufs{};
+    const size_t pieces = (slots + 255) / 256;
+    w.subCap = (uint32_t)(((pieces + rt::kWfStripes - 1) / rt::kWfStripes) * 256);
+    const size_t queueWords = 2 * (size_t)rt::kWfStripes * w.subCap; // positions of both ping-pong halves
+    size_t off = 0;
+    auto take = [&](size_t bytes) -> uint8_t* {
+        uint8_t* p = base ? base + off : nullptr;
+        off += (bytes + 255) & ~(size_t)255;
+        return p;
+    };
+    w.rayO = (float4*)take(16 * queueWords);
+    w.rayD = (float4*)take(16 * queueWords);
+    w.accO = (float4*)take(16 * queueWords);
+    w.accB = (float4*)take(16 * queueWords);
+    w.hitA = (float4*)take(16 * (queueWords / 2));
+    w.hitG = (uint32_t*)take(4 * (queueWords / 2));
+    w.out = (float4*)take(16 * slots);
+    w.outRays = (uint8_t*)take(slots);
+    w.pixFlag = (uint32_t*)take(4 * ((slots + 63) & ~(size_t)63));
+    w.redoList = (uint32_t*)take(4 * ((slots + 63) & ~(size_t)63));
+    w.queue = (uint32_t*)take(4 * queueWords);
+    w.exactList = (uint32_t*)take(4 * (queueWords / 2));
+    w.ctrl = (uint32_t*)take(4 * rt::wf_ctrl_words(levels));
+    return off;
+}
+
 void free_wf(rt_ctx* c)
 {
-    rt::WfBufs& w = c->wf.bufs[0];
-    hipFree(w.rayO); hipFree(w.rayD); hipFree(w.hitA); hipFree(w.hitG); hipFree(w.accO); hipFree(w.accB);
-    hipFree(w.out); hipFree(w.outRays); hipFree(w.pixFlag); hipFree(w.queue); hipFree(w.exactList); hipFree(w.ctrl);
+    hipFree(c->wfArena); c->wfArena = nullptr;
     for (int j = 0; j < rt::kWfMaxLanes; j++) c->wf.bufs[j] = rt::WfBufs{};
     c->wfCapSlots = 0; c->wfLevels = 0; c->wfLanes = 0;
 }
 
-// workspace of the wavefront pipeline: ~180 bytes per sample in flight, `slots` samples per lane
+// workspace of the wavefront pipeline: one arena, `lanes` lanes of `slots` samples each
 hipError_t ensure_wf(rt_ctx* c, size_t slots, int levels, int lanes)
 {
     if (slots <= c->wfCapSlots && levels <= c->wfLevels && lanes <= c->wfLanes) return hipSuccess;
@@ -142,34 +189,11 @@ hipError_t ensure_wf(rt_ctx* c, size_t slots, int levels, int lanes)
     if (levels < c->wfLevels) levels = c->wfLevels;
     if (lanes < c->wfLanes) lanes = c->wfLanes;
     free_wf(c);
-    rt::WfBufs w{};
-    const size_t pieces = (slots + 255) / 256;
-    w.subCap = (uint32_t)(((pieces + rt::kWfStripes - 1) / rt::kWfStripes) * 256);
-    const size_t queueWords = 2 * (size_t)rt::kWfStripes * w.subCap;
-    const size_t ctrlWords = rt::wf_ctrl_words(levels);
-    const size_t all = slots * (size_t)lanes;
-    const size_t allQ = queueWords * (size_t)lanes; // positions of both ping-pong halves, all lanes
-    if (e == hipSuccess) e = hipMalloc((void**)&w.rayO, 16 * allQ);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.rayD, 16 * allQ);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.accO, 16 * allQ);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.accB, 16 * allQ);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.hitA, 16 * (allQ / 2));
-    if (e == hipSuccess) e = hipMalloc((void**)&w.hitG, 4 * (allQ / 2));
-    if (e == hipSuccess) e = hipMalloc((void**)&w.out, 16 * all);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.outRays, all);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.pixFlag, 4 * all);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.queue, sizeof(uint32_t) * queueWords * (size_t)lanes);
-    if (e == hipSuccess) e = hipMalloc((void**)&w.exactList, sizeof(uint32_t) * (allQ / 2));
-    if (e == hipSuccess) e = hipMalloc((void**)&w.ctrl, sizeof(uint32_t) * ctrlWords * (size_t)lanes);
-    c->wf.bufs[0] = w;
-    if (e != hipSuccess) { free_wf(c); return e; }
-    for (int j = 1; j < lanes; j++) {
-        rt::WfBufs v = w;
-        v.rayO += queueWords * j; v.rayD += queueWords * j; v.accO += queueWords * j; v.accB += queueWords * j;
-        v.hitA += (queueWords / 2) * j; v.hitG += (queueWords / 2) * j; v.exactList += (queueWords / 2) * j;
-        v.out += slots * j; v.outRays += slots * j; v.pixFlag += slots * j; v.queue += queueWords * j; v.ctrl += ctrlWords * j;
-        c->wf.bufs[j] = v;
-    }
+    rt::WfBufs w;
+    const size_t perLane = wf_carve(nullptr, slots, levels, w);
+    e = hipMalloc((void**)&c->wfArena, perLane * (size_t)lanes);
+    if (e != hipSuccess) { c->wfArena = nullptr; return e; }
+    for (int j = 0; j < lanes; j++) wf_carve((uint8_t*)c->wfArena + perLane * (size_t)j, slots, levels, c->wf.bufs[j]);
     c->wfCapSlots = slots; c->wfLevels = levels; c->wfLanes = lanes;
     return hipSuccess;
 }
@@ -427,6 +451,16 @@ int rt_texture_destroy(rt_ctx* c, rt_id id)
     RT_BIND(c);
     if (!valid(c->textures, id)) return fail(c, RT_ERR_INVALID, "invalid texture handle");
     RT_CHECK(c, hipStreamSynchronize(c->stream));
+    // the committed tables hold the texel pointer: a committed material that still binds this texture
+    // would sample freed memory, so the scene then has to be committed again before the next rt_render
+    if (c->committed) {
+        for (const rt::DevMaterial& m : c->hMaterials)
+            if (m.texNormal == id || m.texAlbedo == id || m.texRoughness == id || m.texMetal == id) c->committed = false;
+        if (c->committed && (size_t)id < c->capTextures) {
+            const rt::DevTexture none = { nullptr, 0, 0 };
+            RT_CHECK(c, hipMemcpy(c->dTextures + id, &none, sizeof(none), hipMemcpyHostToDevice));
+        }
+    }
     hipFree(c->textures[id].data);
     c->textures[id] = TexRec();
     return RT_OK;
@@ -456,7 +490,11 @@ int rt_material_update(rt_ctx* c, rt_id id, const rt_material_desc* d)
     if (c->committed && (size_t)id < c->capMaterials) {
         const rt::DevMaterial m = to_dev(*d);
         RT_CHECK(c, hipStreamSynchronize(c->stream));
+        // textures created (or re-created in a freed slot) after the commit: bring the device table up to date first
+        r = upload_texture_table(c);
+        if (r) return r;
         RT_CHECK(c, hipMemcpy(c->dMaterials + id, &m, sizeof(m), hipMemcpyHostToDevice));
+        c->hMaterials[id] = m;
     }
     return RT_OK;
 }
@@ -555,16 +593,14 @@ int rt_scene_commit(rt_ctx* c, const rt_id* objects, const float* model16, const
         memset(mats.data(), 0, sizeof(rt::DevMaterial) * mats.size());
         for (size_t i = 0; i < c->materials.size(); i++)
             if (c->materials[i].live) mats[i] = to_dev(c->materials[i].desc);
+            else mats[i].texNormal = mats[i].texAlbedo = mats[i].texRoughness = mats[i].texMetal = -1; // unused slot: binds nothing
+        if (c->materials.empty()) mats[0].texNormal = mats[0].texAlbedo = mats[0].texRoughness = mats[0].texMetal = -1;
         RT_CHECK(c, hipMalloc((void**)&c->dMaterials, sizeof(rt::DevMaterial) * mats.size()));
         RT_CHECK(c, hipMemcpy(c->dMaterials, mats.data(), sizeof(rt::DevMaterial) * mats.size(), hipMemcpyHostToDevice));
         c->capMaterials = mats.size();
-        std::vector<rt::DevTexture> texs(c->textures.size() ? c->textures.size() : 1);
-        memset(texs.data(), 0, sizeof(rt::DevTexture) * texs.size());
-        for (size_t i = 0; i < c->textures.size(); i++)
-            if (c->textures[i].live) { texs[i].data = c->textures[i].data; texs[i].w = c->textures[i].w; texs[i].h = c->textures[i].h; }
-        RT_CHECK(c, hipMalloc((void**)&c->dTextures, sizeof(rt::DevTexture) * texs.size()));
-        RT_CHECK(c, hipMemcpy(c->dTextures, texs.data(), sizeof(rt::DevTexture) * texs.size(), hipMemcpyHostToDevice));
-        c->capTextures = texs.size();
+        c->hMaterials = mats;
+        const int tr = upload_texture_table(c);
+        if (tr) return tr;
     }
 
     rt::Segment* dSegs = nullptr;
@@ -712,13 +748,16 @@ int rt_render(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* 
     memcpy(a.skyDir, sky->direction, 16); memcpy(a.lightColor, sky->lightColor, 16); memcpy(a.skyColor, sky->skyColor, 16);
     a.x0 = tile.x0; a.y0 = tile.y0; a.x1 = tile.x1; a.y1 = tile.y1;
     a.fb = f.data; a.ids = f.idsEnabled ? f.ids : nullptr; a.counters = c->dCounters;
-    // padded to whole 8x8 tiles: the wavefront pipeline gives every chunk the slice [firstTile * 64, ...)
-    const size_t tilePixels = (size_t)((tile.x1 - tile.x0 + 7) / 8) * (size_t)((tile.y1 - tile.y0 + 7) / 8) * 64;
-    if (tilePixels > c->redoCap) { // grows only when a larger tile than ever before is rendered
-        RT_CHECK(c, hipStreamSynchronize(c->stream));
-        hipFree(c->dRedoList); c->dRedoList = nullptr; c->redoCap = 0;
-        RT_CHECK(c, hipMalloc((void**)&c->dRedoList, sizeof(uint32_t) * tilePixels));
-        c->redoCap = tilePixels;
+    const bool wavefront = c->optTraversal == 0 && rnd->bounceCount <= 200;
+    if (c->optTraversal == 2 || (c->optTraversal == 0 && !wavefront)) {
+        // persistent path kernel: one redo list over the tile's pixels (the wavefront pipeline keeps its own per lane)
+        const size_t tilePixels = (size_t)((tile.x1 - tile.x0 + 7) / 8) * (size_t)((tile.y1 - tile.y0 + 7) / 8) * 64;
+        if (tilePixels > c->redoCap) { // grows only when a larger tile than ever before is rendered
+            RT_CHECK(c, hipStreamSynchronize(c->stream));
+            hipFree(c->dRedoList); c->dRedoList = nullptr; c->redoCap = 0;
+            RT_CHECK(c, hipMalloc((void**)&c->dRedoList, sizeof(uint32_t) * tilePixels));
+            c->redoCap = tilePixels;
+        }
     }
     a.tileCounters = c->dWork; a.redoCount = c->dWork + 256; a.redoList = c->dRedoList;
     a.pixelList = nullptr; a.pixelCount = nullptr;
@@ -728,7 +767,7 @@ int rt_render(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* 
     RT_CHECK(c, hipEventRecord(c->evBegin, c->stream));
     // mode 0: wavefront pipeline (the single persistent kernel, mode 2, remains for very deep paths:
     // the per-sample query count of the pipeline is a byte)
-    if (c->optTraversal == 0 && rnd->bounceCount <= 200) {
+    if (wavefront) {
         const size_t tiles = (size_t)((tile.x1 - tile.x0 + 7) / 8) * (size_t)((tile.y1 - tile.y0 + 7) / 8);
         const size_t perTile = 64 * (size_t)rnd->sampleCount;
         if (perTile >= (1ull << 31)) return fail(c, RT_ERR_INVALID, "sampleCount too large for one 8x8 tile of the wavefront workspace");
@@ -770,7 +809,7 @@ int rt_trace_rays(rt_ctx* c, const float* rays, int32_t n, uint32_t* out)
     RT_CHECK(c, hipMalloc((void**)&dr, 32 * (size_t)n));
     hipError_t e = hipMalloc((void**)&dout, 16 * (size_t)n);
     if (e == hipSuccess) e = hipMemcpyAsync(dr, rays, 32 * (size_t)n, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(c->dCounters, 0, kCntBytes, c->stream);
+    if (e == hipSuccess && !c->optAccumulate) e = hipMemsetAsync(c->dCounters, 0, kCntBytes, c->stream);
     if (e == hipSuccess) {
         rt::launch_trace_rays(scene_view(c), dr, n, dout, c->dCounters, c->optTraversal, c->stream);
         e = hipGetLastError();

@@ -127,6 +127,7 @@ struct WfBufs {
     float4* out;         // [slot] finished sample: exposure-corrected rgb, checksum bits
     uint8_t* outRays;    // [slot] closest-hit queries of the finished sample
     uint32_t* pixFlag;   // [pixelInChunk] != 0: flagged for the redo launch
+    uint32_t* redoList;  // [pixelInChunk] the chunk's flagged pixels (a lane's chunks run one after the other, so they share it)
     uint32_t* queue;     // [2][kWfStripes][subCap] slots, ping-pong over levels
     uint32_t* exactList; // [kWfStripes][subCap] hit positions of the rays of the current level that need the exact emulation, listed per stripe
     uint32_t* ctrl;      // [level][2][kWfStripes][kWfCtrlStride]: counts, cursors; then the redo count; then per level one exact count per stripe (one same-address atomic stream per stripe: a single counter capped the trace kernels at its ~90 appends per microsecond)

@@ -1417,7 +1417,7 @@ void launch_render_wf(const RenderArgs& a, const WfLanes& L, int numCUs, hipStre
         const uint32_t nPieces = (w.nSlots + 255u) / 256u;
         RenderArgs c = b;
         c.redoCount = w.ctrl + wf_ctrl_redo(levels);
-        c.redoList = b.redoList + (size_t)k * tilesPerChunk * 64u;
+        c.redoList = w.redoList; // per lane: at most the chunk's own pixels are listed, and the lane's chunks run in stream order
         hipMemsetAsync(w.ctrl, 0, sizeof(uint32_t) * ctrlWords, stream);
         hipLaunchKernelGGL(wf_gen_kernel, dim3(nPieces), dim3(256), 0, stream, c, w);
         uint32_t gridT = (uint32_t)numCUs * RT_WF_OCC;
