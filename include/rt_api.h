@@ -153,6 +153,18 @@ int rt_framebuffer_read_ids(rt_ctx* ctx, rt_id fb, uint32_t* host_ids);
 int rt_render(rt_ctx* ctx, const rt_camera_params* camera, const rt_renderer_params* renderer,
               const rt_sky_params* sky, rt_rect tile, rt_id fb);
 
+/* rt_render for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  It has no counterpart in the reference.  Same arguments, same pixels, ids and statistics as
+ * rt_render with RT_OPT_TRAVERSAL = 0, but the wavefront workspace (path state, queues, hit records, redo lists)
+ * lives in a 64 MiB static device array that every GPU the library runs on holds until the process ends, and the
+ * call makes no hipMalloc / hipFree: the frame is rendered in as many consecutive chunks as that array needs
+ * (~350 000 samples each), on the context stream.  Limits, rejected with RT_ERR_INVALID: bounceCount <= 16;
+ * sampleCount <= ~5 000 (64 * sampleCount samples, one 8x8 tile, must fit).  The scene, the ray table and the
+ * framebuffer must exist already.  Every call on a GPU shares that GPU's array: calls that overlap on one GPU
+ * (two contexts, two streams) race; calls in stream order do not. */
+int rt_render_noalloc(rt_ctx* ctx, const rt_camera_params* camera, const rt_renderer_params* renderer,
+                      const rt_sky_params* sky, rt_rect tile, rt_id fb);
+
 /* closest-hit queries for caller-supplied rays (GPURaytracer.cu:247-265 semantics).
  * rays: 8 floats each (origin xyz, maxDistance, direction xyz, pad); out: 4 uint32 each
  * (object, mesh, triangle, float bits of t; all 0xFFFFFFFF on miss).  Host pointers. */

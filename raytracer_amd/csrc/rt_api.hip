@@ -5,6 +5,7 @@
 #include "rt_detmath.h"
 
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -16,6 +17,17 @@ constexpr int kWfLanesDefault = 3;        // most chunks in flight: the process 
 constexpr size_t kCntBytes = sizeof(unsigned long long) * rt::kCounterSlots * rt::kCounterStride;
 
 thread_local std::string g_createError;
+
+// ---- static workspace of rt_render_noalloc (callers that cannot allocate: HIP graph capture, serving loops) ----
+// One copy per GPU, held until the process ends.  `scratch` is only a host-side stand-in for the symbol: its
+// device address on each GPU is taken once with hipGetSymbolAddress (rt_ctx_create, that device current) and every
+// use below goes through that pointer.
+constexpr size_t kScratchBytes = 64ull << 20;   // 64 MiB
+constexpr int kScratchMaxLevels = 16;           // bounceCount limit of rt_render_noalloc
+constexpr int kScratchMaxDevices = 64;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+std::mutex g_scratchMutex;
+void* g_scratchPtr[kScratchMaxDevices] = {};    // [device] address of that GPU's copy of `scratch`
 
 struct MeshRec {
     bool live = false;
@@ -72,6 +84,7 @@ struct rt_ctx {
     int numCUs = 256;
     uint32_t* dWork = nullptr;      // 8 tile counters (32 words apart) + redo count at word 256
     uint32_t* dRedoList = nullptr; size_t redoCap = 0;
+    void* scratchPtr = nullptr;     // this device's copy of the static workspace (rt_render_noalloc)
 };
 
 namespace {
@@ -272,8 +285,19 @@ int rt_ctx_create(int device, rt_ctx** out)
     if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
         return fail(nullptr, RT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library holds gfx950 code only");
     RT_CHECK(nullptr, hipSetDevice(device));
+    void* scratchPtr = nullptr;
+    if (device < kScratchMaxDevices) { // every GPU holds its own copy of the array at its own address
+        std::lock_guard<std::mutex> lock(g_scratchMutex);
+        if (!g_scratchPtr[device]) {
+            void* p = nullptr;
+            RT_CHECK(nullptr, hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+            g_scratchPtr[device] = p;
+        }
+        scratchPtr = g_scratchPtr[device];
+    }
     rt_ctx* c = new rt_ctx();
     c->device = device;
+    c->scratchPtr = scratchPtr;
     c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     hipError_t e = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void**)&c->dCounters, kCntBytes);
@@ -722,12 +746,12 @@ int rt_framebuffer_read_ids(rt_ctx* c, rt_id id, uint32_t* host)
     return RT_OK;
 }
 
-int rt_render(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* rnd, const rt_sky_params* sky, rt_rect tile,
-              rt_id fb)
+// argument checks and parameter packing shared by rt_render and rt_render_noalloc
+static int render_args(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* rnd, const rt_sky_params* sky,
+                       rt_rect tile, rt_id fb, const char* who, rt::RenderArgs& a)
 {
-    RT_BIND(c);
     if (!cam || !rnd || !sky) return fail(c, RT_ERR_INVALID, "null parameter block");
-    if (!c->committed) return fail(c, RT_ERR_STATE, "rt_render before rt_scene_commit");
+    if (!c->committed) return fail(c, RT_ERR_STATE, std::string(who) + " before rt_scene_commit");
     if (!valid(c->fbs, fb)) return fail(c, RT_ERR_INVALID, "invalid framebuffer handle");
     const FbRec& f = c->fbs[fb];
     if (cam->width != f.w || cam->height != f.h) return fail(c, RT_ERR_INVALID, "camera extents differ from the framebuffer's");
@@ -737,7 +761,6 @@ int rt_render(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* 
         return fail(c, RT_ERR_INVALID, "tile outside the framebuffer");
     if (rnd->sampleCount == 0) return fail(c, RT_ERR_INVALID, "sampleCount must be at least 1");
 
-    rt::RenderArgs a;
     memset(&a, 0, sizeof(a));
     a.scene = scene_view(c);
     memcpy(a.camOrigin, cam->origin, 16); memcpy(a.camRotation, cam->rotation, 16);
@@ -748,6 +771,18 @@ int rt_render(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* 
     memcpy(a.skyDir, sky->direction, 16); memcpy(a.lightColor, sky->lightColor, 16); memcpy(a.skyColor, sky->skyColor, 16);
     a.x0 = tile.x0; a.y0 = tile.y0; a.x1 = tile.x1; a.y1 = tile.y1;
     a.fb = f.data; a.ids = f.idsEnabled ? f.ids : nullptr; a.counters = c->dCounters;
+    a.tileCounters = c->dWork; a.redoCount = c->dWork + 256; a.redoList = nullptr;
+    a.pixelList = nullptr; a.pixelCount = nullptr;
+    return RT_OK;
+}
+
+int rt_render(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* rnd, const rt_sky_params* sky, rt_rect tile,
+              rt_id fb)
+{
+    RT_BIND(c);
+    rt::RenderArgs a;
+    const int rc = render_args(c, cam, rnd, sky, tile, fb, "rt_render", a);
+    if (rc) return rc;
     const bool wavefront = c->optTraversal == 0 && rnd->bounceCount <= 200;
     if (c->optTraversal == 2 || (c->optTraversal == 0 && !wavefront)) {
         // persistent path kernel: one redo list over the tile's pixels (the wavefront pipeline keeps its own per lane)
@@ -759,8 +794,7 @@ int rt_render(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* 
             c->redoCap = tilePixels;
         }
     }
-    a.tileCounters = c->dWork; a.redoCount = c->dWork + 256; a.redoList = c->dRedoList;
-    a.pixelList = nullptr; a.pixelCount = nullptr;
+    a.redoList = c->dRedoList;
     RT_CHECK(c, hipMemsetAsync(c->dWork, 0, kWorkBytes, c->stream));
 
     if (!c->optAccumulate) RT_CHECK(c, hipMemsetAsync(c->dCounters, 0, kCntBytes, c->stream));
@@ -792,6 +826,54 @@ int rt_render(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* 
         }
     } else {
         rt::launch_render(a, c->optTraversal == 1 ? 1 : 0, c->numCUs, c->stream);
+    }
+    RT_CHECK(c, hipGetLastError());
+    RT_CHECK(c, hipEventRecord(c->evEnd, c->stream));
+    c->renderedOnce = true;
+    return RT_OK;
+}
+
+// largest sample count per chunk whose workspace (wf_carve) fits the static array
+static size_t scratch_slots(int levels)
+{
+    rt::WfBufs w;
+    size_t lo = 0, hi = kScratchBytes / 64;   // slots, in units of one 8x8 tile at 1 spp
+    while (lo < hi) {
+        const size_t mid = (lo + hi + 1) / 2;
+        if (wf_carve(nullptr, mid * 64, levels, w) <= kScratchBytes) lo = mid; else hi = mid - 1;
+    }
+    return lo * 64;
+}
+
+int rt_render_noalloc(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* rnd, const rt_sky_params* sky,
+                      rt_rect tile, rt_id fb)
+{
+    RT_BIND(c);
+    rt::RenderArgs a;
+    const int rc = render_args(c, cam, rnd, sky, tile, fb, "rt_render_noalloc", a);
+    if (rc) return rc;
+    if (!c->scratchPtr) return fail(c, RT_ERR_STATE, "rt_render_noalloc: no static workspace on this device index");
+    if (rnd->bounceCount > kScratchMaxLevels)
+        return fail(c, RT_ERR_INVALID, "rt_render_noalloc: bounceCount beyond the maximum of 16");
+    const int levels = rnd->bounceCount > 0 ? rnd->bounceCount : 0;
+    const size_t capSlots = scratch_slots(levels);
+    const size_t perTile = 64 * (size_t)rnd->sampleCount;
+    if (perTile > capSlots)
+        return fail(c, RT_ERR_INVALID, "rt_render_noalloc: sampleCount beyond the maximum of " + std::to_string(capSlots / 64) +
+                                           " at this bounceCount (the samples of one 8x8 tile must fit the 64 MiB static workspace)");
+    const size_t tiles = (size_t)((tile.x1 - tile.x0 + 7) / 8) * (size_t)((tile.y1 - tile.y0 + 7) / 8);
+    RT_CHECK(c, hipMemsetAsync(c->dWork, 0, kWorkBytes, c->stream));
+    if (!c->optAccumulate) RT_CHECK(c, hipMemsetAsync(c->dCounters, 0, kCntBytes, c->stream));
+    RT_CHECK(c, hipEventRecord(c->evBegin, c->stream));
+    if (tiles > 0) {
+        // one lane on the caller's stream; the chunks (whole tiles, as many as fit) run one after the other, each
+        // clearing the control words it needs at its start (launch_render_wf), so nothing of the last call is read
+        size_t chunkTiles = capSlots / perTile;
+        if (chunkTiles > tiles) chunkTiles = tiles;
+        rt::WfLanes L = c->wf;
+        L.n = 1; L.tilesPerChunk = (uint32_t)chunkTiles;
+        wf_carve((uint8_t*)c->scratchPtr, chunkTiles * perTile, levels, L.bufs[0]);
+        rt::launch_render_wf(a, L, c->numCUs, c->stream);
     }
     RT_CHECK(c, hipGetLastError());
     RT_CHECK(c, hipEventRecord(c->evEnd, c->stream));
