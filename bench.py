@@ -3,16 +3,24 @@
 queries, GPURaytracer.cu:247 calls) on BASELINE.json configs[1] (low-poly model, 1920x1080,
 16 spp, depth 4) unless --workload says otherwise.
 
-One "step" = one frame (one pass of the hot path over W*H*spp samples) per GPU.  With N > 1 the
-ranks split frame indices (progressive accumulation): rank r renders frame
-step*N + r of the replicated scene and the clamped frames are combined with one RCCL
-reduce(SUM) per step, inside the timed region.  Per-GPU work is fixed => weak scaling.
-`--mode tiles` instead splits ONE frame into interleaved row bands (strong scaling) and
-all-gathers them.
+One "step" = one frame (one pass of the hot path over W*H*spp samples).
+ * frames mode (default): with N > 1 the ranks split frame indices (progressive accumulation):
+   rank r renders frame step*N + r of the replicated scene and the clamped frames are combined with one RCCL
+   reduce(SUM) per step, inside the timed region.  Per-GPU work is fixed => weak scaling.
+ * tiles mode: ONE frame per step, split into interleaved 64-row bands (rt_render_bands: a rank's bands are one
+   pass of the pipeline), composited with one all_gather => strong scaling.  This is the partitioning
+   BASELINE.json's north_star names for configs[3] (C4).
 
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and
-`cpu_baseline` objects.  The CPU baseline is the oracle (reference kernel logic, brute force)
-on a bounded centred crop of the same workload; it is a reported baseline, not the target.
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and `cpu_baseline`
+objects, and under "also" the same measurement of C4 (1 M triangles, 4K: the north-star target config) --
+at N = 1 as a whole frame, at N > 1 through the tile split.  The CPU baseline is the oracle (reference kernel
+logic, brute force) on a bounded centred crop of the same workload; it is a reported baseline, not the target.
+
+roofline follows SURVEY.md 8(d): algorithmic bytes per ray = node fetches x 64 B + triangle tests x 48 B +
+hits x (12 + 96 + 16 per bound map) B + 16 B per pixel of output (+ 16 read when progressive); flops per ray =
+node tests x 30 + triangle tests x 45 + hits x 300.  The wavefront pipeline's own path-state traffic is NOT
+algorithmic and is reported beside it (state_bytes_per_ray).  `frac` is the larger of the HBM and FP32-vector
+fractions, as 8(d) defines it; `bound` says what the counters say actually limits the kernels.
 """
 import argparse
 import json
@@ -27,6 +35,12 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
+NODE_B, TRI_B = 64.0, 48.0                 # one four-wide BVH node; 3 x i32 + 3 x 3 x f32 per triangle test (8d)
+HIT_B, MAP_B = 12.0 + 96.0, 16.0           # per shaded hit: 3 indices + 3 x (12 + 12 + 8) B attributes; 4 texels x 4 B per bound map
+NODE_F, TRI_F, HIT_F = 30.0, 45.0, 300.0   # flop per node test / triangle test / shaded hit (8d)
+# path state crossing HBM between the launches of the wavefront pipeline, per closest-hit query (not algorithmic):
+# trace: ray 32 + queue 4 in, hit 20 out; shade: ray 32 + hit 20 + state 32 + queue 4 in, ray 32 + state 32 + queue 4 out
+STATE_B = (32 + 4 + 20) + (32 + 20 + 32 + 4) + (32 + 32 + 4)
 
 
 def build_workload(name, args):
@@ -44,113 +58,104 @@ def build_workload(name, args):
         names = fn.__code__.co_varnames[:fn.__code__.co_argcount]
         given = {"width": args.width, "height": args.height, "spp": args.spp, "depth": args.depth}
         scene, cam, st = fn(**{k: v for k, v in given.items() if v and k in names})
-        label = fn.__doc__.strip().split("\n")[0]
+        label = scenes.workload_label(name) if hasattr(scenes, "workload_label") else fn.__doc__.strip().split("\n")[0]
     return scene, cam, st, label
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2")
-    ap.add_argument("--mode", default="frames", choices=["frames", "tiles"])
-    ap.add_argument("--width", type=int, default=0)
-    ap.add_argument("--height", type=int, default=0)
-    ap.add_argument("--spp", type=int, default=0)
-    ap.add_argument("--depth", type=int, default=0)
-    ap.add_argument("--cpu-crop", type=int, default=448, help="side of the centred crop the CPU baseline renders")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--brute", action="store_true", help="reference-order brute force instead of the BVH")
-    ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "persistent"],
-                    help="BVH render pipeline: per-bounce trace/shade launches (default) or the single persistent kernel")
-    ap.add_argument("--wf-lanes", type=int, default=0, help="chunks in flight (HIP streams) of the wavefront pipeline (0 = library default)")
-    ap.add_argument("--builder", type=int, default=0, help="acceleration structure builder: 0 = PLOC (library default), 1 = radix tree")
-    ap.add_argument("--wf-chunk", type=int, default=0, help="samples in flight per chunk of the wavefront pipeline (0 = library default)")
-    args = ap.parse_args()
+class Job:
+    """Shared state of one bench process: torch / RCCL, the context, its stream."""
 
-    import torch
-    import torch.distributed as dist
-    from raytracer_amd import capi, multigpu
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        from raytracer_amd import capi, multigpu
+        self.torch, self.dist, self.capi, self.multigpu, self.args = torch, dist, capi, multigpu, args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus and self.world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run (see the task contract)")
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device("cuda", self.local_rank)
+        self.ctx = capi.Context(self.local_rank)
+        # a real (non-null) stream shared by torch and librt_amd: rt_set_stream(NULL) would mean the
+        # context's own stream, and the legacy default stream's handle IS null
+        self.stream = torch.cuda.Stream(device=self.dev)
+        torch.cuda.set_stream(self.stream)
+        self.ctx.set_stream(self.stream.cuda_stream)
+        self.ctx.set_option(capi.OPT_TRAVERSAL, 1 if args.brute else (0 if args.pipeline == "wavefront" else 2))
+        if args.wf_lanes:
+            self.ctx.set_option(capi.OPT_WF_LANES, args.wf_lanes)
+        if args.builder:
+            self.ctx.set_option(capi.OPT_BUILDER, args.builder)
+        if args.wf_chunk:
+            self.ctx.set_option(capi.OPT_WF_CHUNK, args.wf_chunk)
 
-    scene, cam, st, label = build_workload(args.workload, args)
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+
+def measure(job, workload, mode, steps, warmup, cpu_baseline):
+    """W untimed + K timed steps of one workload; returns the JSON object (rank 0) or None."""
+    torch, dist, capi, multigpu, args, ctx = job.torch, job.dist, job.capi, job.multigpu, job.args, job.ctx
+    rank, world, dev = job.rank, job.world, job.dev
+    scene, cam, st, label = build_workload(workload, args)
     W, H = cam.width, cam.height
     flat = scene.flatten()
-
-    ctx = capi.Context(local_rank)
-    # a real (non-null) stream shared by torch and librt_amd: rt_set_stream(NULL) would mean the
-    # context's own stream, and the legacy default stream's handle IS null
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
-    ctx.set_stream(stream.cuda_stream)
-    ctx.set_option(capi.OPT_TRAVERSAL, 1 if args.brute else (0 if args.pipeline == "wavefront" else 2))
-    if args.wf_lanes:
-        ctx.set_option(capi.OPT_WF_LANES, args.wf_lanes)
-    if args.builder:
-        ctx.set_option(capi.OPT_BUILDER, args.builder)
-    if args.wf_chunk:
-        ctx.set_option(capi.OPT_WF_CHUNK, args.wf_chunk)
     t0 = time.time()
     ctx.upload_scene(flat)
     upload_s = time.time() - t0
     ctx.set_camera_rays(cam.preTransformRays)
-    fb_t = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
-    acc_t = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
-    fb = ctx.framebuffer_wrap(fb_t.data_ptr(), W, H)
-    # frames mode: two buffers, so that the RCCL reduce of one frame runs while the next one renders
-    fb_t2 = torch.zeros((H, W, 4), dtype=torch.float32, device=dev) if args.mode == "frames" else None
-    fb2 = ctx.framebuffer_wrap(fb_t2.data_ptr(), W, H) if fb_t2 is not None else None
-    fa = multigpu.FrameAccumulator(dist, world, rank, [fb_t, fb_t2], acc_t) if args.mode == "frames" else None
 
-    if args.mode == "tiles":
-        rects = multigpu.band_rects(W, H, rank, world)
+    fa = tc = None
+    if mode == "frames":
+        # two buffers, so that the RCCL reduce of one frame runs while the next one renders
+        bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device=dev) for _ in range(2)]
+        acc_t = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+        fbs = [ctx.framebuffer_wrap(b.data_ptr(), W, H) for b in bufs]
+        fa = multigpu.FrameAccumulator(dist, world, rank, bufs, acc_t)
+        frame_t = bufs[0]
     else:
-        rects = [(0, 0, W, H)]
+        tc = multigpu.TileCompositor(torch, dist, W, H, rank, world, dev)
+        fbs = [ctx.framebuffer_wrap(tc.frame.data_ptr(), W, H)]
+        frame_t = tc.frame
 
     def step(frame_base):
         st.progressiveFrameCount = 0
-        if args.mode == "frames":
+        if mode == "frames":
             st.frameCount = frame_base * world + rank
             b = fa.acquire(frame_base)
-            ctx.render(cam, st, (fb, fb2)[b], rects[0])
+            ctx.render(cam, st, fbs[b])
             fa.submit(b)
         else:
             st.frameCount = frame_base
-            for r in rects:
-                ctx.render(cam, st, fb, r)
             if world > 1:
-                multigpu.composite_tiles(dist, fb_t, W, H, rank, world)
+                ctx.render(cam, st, fbs[0], bands=(multigpu.BAND_ROWS, rank, world))
+                tc.composite()
+            else:
+                ctx.render(cam, st, fbs[0])
 
     def barrier():
         if fa is not None:
             fa.drain()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        job.barrier()
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
     barrier()
     ctx.set_option(capi.OPT_ACCUMULATE_STATS, 1)
     barrier()
     ctx.event_record(0)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    for i in range(steps):
+        step(warmup + i)
     if fa is not None:
         fa.drain()
     ctx.event_record(1)
@@ -173,91 +178,132 @@ def main():
 
     out = None
     if rank == 0:
-        launches = args.steps * len(rects)
-        kernel_ms = gpu_ms / launches  # HIP events on the launch stream over the timed region
-        node_b, tri_b, shade_b = 64.0, 48.0, 48.0 + 80.0 + 64.0
-        tex_per_hit = sum(16.0 for m in flat.materials for k in ("texNormal", "texAlbedo", "texRoughness", "texMetal")
-                          if m[k] >= 0) / max(1, len(flat.materials))
-        samples_local = W * H * st.sampleCount * args.steps if args.mode == "frames" else sum(
-            (r[2] - r[0]) * (r[3] - r[1]) for r in rects) * st.sampleCount * args.steps
-        pix_local = samples_local / st.sampleCount
-        # wavefront pipeline: per closest-hit query the path state crosses HBM between the launches
-        # (trace: ray 32 + queue 4 in, hit 20 out; shade: ray 32 + hit 20 + state 32 + queue 4 in,
-        # ray 32 + state 32 + queue 4 out) and per sample 16 + 1 bytes of result out and in again
-        state_b = (32 + 4 + 20) + (32 + 20 + 32 + 4) + (32 + 32 + 4) if args.pipeline == "wavefront" and not args.brute else 0.0
+        wavefront = args.pipeline == "wavefront" and not args.brute
+        kernel_ms = gpu_ms / steps  # HIP events on the launch stream over the timed region; one rt_render(_bands) per step
+        maps_per_hit = sum(1.0 for m in flat.materials for k in ("texNormal", "texAlbedo", "texRoughness", "texMetal")
+                           if m[k] >= 0) / max(1, len(flat.materials))
+        pix_local = float(W) * H * steps / (world if mode == "tiles" else 1)
         # a packet of 64 camera rays fetches a node once (scalar load) and tests it per ray
         node_fetches = s.node_visits - s.packet_node_tests + s.packet_node_fetches
-        alg_bytes = (node_fetches * node_b + s.tri_tests * tri_b + s.hits * (shade_b + tex_per_hit)
-                     + rays_local * state_b + samples_local * (64.0 + (34.0 if state_b else 0.0)) + pix_local * 16.0)
-        alg_flops = s.node_visits * 44.0 + s.tri_tests * 45.0 + s.hits * 300.0 + samples_local * 60.0
-        achieved_gbs = alg_bytes / launches / (kernel_ms * 1e-3) / 1e9
-        achieved_tf = alg_flops / launches / (kernel_ms * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("workload") == args.workload and not args.brute:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        alg_bytes = (node_fetches * NODE_B + s.tri_tests * TRI_B + s.hits * (HIT_B + MAP_B * maps_per_hit) + pix_local * 16.0)
+        alg_flops = s.node_visits * NODE_F + s.tri_tests * TRI_F + s.hits * HIT_F
+        hbm_gbs = alg_bytes / steps / (kernel_ms * 1e-3) / 1e9
+        valu_tf = alg_flops / steps / (kernel_ms * 1e-3) / 1e12
+        hbm_frac, valu_frac = hbm_gbs / HBM_PEAK_GBS, valu_tf / FP32_PEAK_TFLOPS
+        by_hbm = hbm_frac >= valu_frac
+        nr = max(1, rays_local)
         out = {
             "metric": "Mrays/s (primary+bounce closest-hit queries)",
             "value": rays_total / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak" if args.mode == "frames" else "strong",
+            "scaling": "weak" if mode == "frames" else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": label, "width": W, "height": H, "spp": int(st.sampleCount),
                        "depth": int(st.bounceCount), "triangles": int(s.triangles), "objects": len(flat.objects),
-                       "mode": args.mode, "traversal": "brute" if args.brute else "bvh", "pipeline": args.pipeline,
-                       "rays_per_frame": rays_local / args.steps, "scene_upload_s": upload_s,
-                       "bvh_build_ms": float(s.commit_ms)},
-            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("all launches of one rt_render call (wf_gen, wf_trace + wf_shade per bounce level, wf_resolve, redo); "
-                                    "wf_trace dominates, see profiles/") if args.pipeline == "wavefront" and not args.brute
-                         else ("path_kernel + redo" if not args.brute else "render_kernel (brute force)"),
-                         "kernel_ms": kernel_ms,
-                         "bytes_per_ray": alg_bytes / max(1, rays_local), "nodes_per_ray": s.node_visits / max(1, rays_local),
-                         "node_fetches_per_ray": node_fetches / max(1, rays_local),
-                         "tris_per_ray": s.tri_tests / max(1, rays_local), "slow_path_frac": s.slow_path / max(1, rays_local),
-                         "valu": {"achieved": achieved_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": achieved_tf / FP32_PEAK_TFLOPS, "flop_per_ray": alg_flops / max(1, rays_local)}},
+                       "mode": mode, "traversal": "brute" if args.brute else "bvh", "pipeline": args.pipeline,
+                       "rays_per_frame": rays_total / steps / (world if mode == "frames" else 1), "scene_upload_s": upload_s,
+                       "bvh_build_ms": float(s.commit_ms), "lib": ctx.L.rt_version().decode()},
+            "roofline": {
+                # what the counters show (profiles/): VALU issue slots 70-85 % full at partial lane
+                # use in the trace kernels, L2 latency in wf_shade; HBM bandwidth is not the limit at these scene sizes
+                "bound": "valu-issue at partial lane use + L2 latency (not HBM bandwidth; see profiles/)",
+                "achieved": hbm_gbs if by_hbm else valu_tf, "peak": HBM_PEAK_GBS if by_hbm else FP32_PEAK_TFLOPS,
+                "unit": "GB/s" if by_hbm else "TFLOP/s", "frac": max(hbm_frac, valu_frac),
+                # HBM bytes per launch come from separate rocprofv3 --pmc passes (profiles/traffic.json names the build
+                # they were taken on); they are not measurable from inside this run, so none is claimed here
+                "traffic": None,
+                "kernel": ("all launches of one rt_render call (wf_gen, wf_trace + wf_shade per bounce level, wf_resolve, redo)"
+                           if wavefront else ("path_kernel + redo" if not args.brute else "render_kernel (brute force)")),
+                "kernel_ms": kernel_ms,
+                "hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac, "bytes_per_ray": alg_bytes / nr},
+                "valu": {"achieved": valu_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": valu_frac, "flop_per_ray": alg_flops / nr},
+                # the pipeline's own HBM traffic per query: ray / hit / accumulator records between launches + 34 B per sample of result
+                "state_bytes_per_ray": (float(STATE_B) + 34.0 * st.sampleCount * pix_local / nr) if wavefront else 0.0,
+                "nodes_per_ray": s.node_visits / nr, "node_fetches_per_ray": node_fetches / nr,
+                "tris_per_ray": s.tri_tests / nr, "hits_per_ray": s.hits / nr, "slow_path_frac": s.slow_path / nr},
         }
-        if not args.no_cpu_baseline and world == 1:   # the CPU leg runs at N = 1 only
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath)).get(workload)
+                if tj and not args.brute and wavefront:
+                    out["roofline"]["traffic_profile"] = {"file": "profiles/traffic.json", "lib": tj.get("lib"),
+                                                          "same_build": tj.get("lib") == ctx.L.rt_version().decode(),
+                                                          "hbm_bytes_per_launch": tj.get("hbm_bytes_per_launch")}
+            except Exception:
+                pass
+        if cpu_baseline:
             from oracle import oracle_py as orc
             # bounded sample: the oracle is brute force (every ray tests every triangle of every object it does
             # not cull), so the crop shrinks with the scene to keep the CPU leg around 10-30 s
             budget = 2.2e10
             c = int(min(args.cpu_crop, W, H, max(8.0, (budget / (st.sampleCount * 1.8 * max(1, int(s.triangles)))) ** 0.5)))
             x0, y0 = (W - c) // 2, (H - c) // 2
-            st.frameCount = args.warmup * (world if args.mode == "frames" else 1)
+            st.frameCount = warmup
             st.progressiveFrameCount = 0
             threads = orc.lib().or_num_threads()
-            tc = time.perf_counter()
+            tcpu = time.perf_counter()
             ref, _, nq = orc.render(flat, cam, st, rect=(x0, y0, x0 + c, y0 + c), want_ids=False)
-            cpu_s = time.perf_counter() - tc
+            cpu_s = time.perf_counter() - tcpu
             # same frame on the GPU for a live parity figure on the crop
-            ctx.render(cam, st, fb, (x0, y0, x0 + c, y0 + c))
+            ctx.render(cam, st, fbs[0], (x0, y0, x0 + c, y0 + c))
             ctx.sync()
-            g = fb_t[y0:y0 + c, x0:x0 + c, :3].cpu().numpy()
+            g = frame_t[y0:y0 + c, x0:x0 + c, :3].cpu().numpy()
             err = float(np.abs(g - ref[y0:y0 + c, x0:x0 + c, :3]).max())
             out["cpu_baseline"] = {"value": nq / cpu_s / 1e6, "unit": "Mrays/s", "cores": int(threads), "kind": "port",
                                    "sample": f"centred {c}x{c} crop of frame {st.frameCount}, {st.sampleCount} spp, "
                                              f"depth {st.bounceCount}: {nq} rays in {cpu_s:.1f} s",
                                    "gpu_vs_oracle_max_abs_on_crop": err}
+    for fb in fbs:
+        ctx.framebuffer_destroy(fb)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2")
+    ap.add_argument("--mode", default="", choices=["", "frames", "tiles"],
+                    help="default: frames (weak scaling) for the headline workload; the C4 line under `also` uses tiles when N > 1")
+    ap.add_argument("--also", default="c4", help="second workload measured in the same run and reported under `also` ('' = none)")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--spp", type=int, default=0)
+    ap.add_argument("--depth", type=int, default=0)
+    ap.add_argument("--cpu-crop", type=int, default=448, help="side of the centred crop the CPU baseline renders")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--brute", action="store_true", help="reference-order brute force instead of the BVH")
+    ap.add_argument("--pipeline", default="wavefront", choices=["wavefront", "persistent"],
+                    help="BVH render pipeline: per-bounce trace/shade launches (default) or the single persistent kernel")
+    ap.add_argument("--wf-lanes", type=int, default=0, help="chunks in flight (HIP streams) of the wavefront pipeline (0 = library default)")
+    ap.add_argument("--builder", type=int, default=0, help="acceleration structure builder: 0 = PLOC (library default), 1 = radix tree")
+    ap.add_argument("--wf-chunk", type=int, default=0, help="samples in flight per chunk of the wavefront pipeline (0 = library default)")
+    args = ap.parse_args()
+
+    job = Job(args)
+    mode = args.mode or "frames"
+    out = measure(job, args.workload, mode, args.steps, args.warmup, cpu_baseline=not args.no_cpu_baseline and job.world == 1)
+    custom = bool(args.width or args.height or args.spp or args.depth or args.brute)
+    if args.also and args.also != args.workload and not custom:
+        # the north-star target config: one GPU renders the whole frame, N > 1 split it by image tiles
+        also = measure(job, args.also, "tiles", args.steps, args.warmup, cpu_baseline=False)
+        if out is not None and also is not None:
+            out["also"] = [{k: also[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "scaling", "config", "roofline")}]
+    if job.rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    ctx.close()
+    if job.world > 1:
+        job.dist.barrier()
+        job.dist.destroy_process_group()
+    job.ctx.close()
 
 
 if __name__ == "__main__":

@@ -153,6 +153,15 @@ int rt_framebuffer_read_ids(rt_ctx* ctx, rt_id fb, uint32_t* host_ids);
 int rt_render(rt_ctx* ctx, const rt_camera_params* camera, const rt_renderer_params* renderer,
               const rt_sky_params* sky, rt_rect tile, rt_id fb);
 
+/* The image-tile split of one frame over several GPUs (no counterpart in the single-GPU reference; the pixels are those
+ * of rt_render): `tile` is cut into bands of bandRows rows (a multiple of 8; band b = rows [y0 + b*bandRows, ...)) and
+ * this call renders bands firstBand, firstBand + bandStride, ...  -- rank r of n calls it with (firstBand, bandStride) =
+ * (r, n); interleaving balances sky against geometry.  The bands of a call run as ONE pass of the pipeline, not one per
+ * band.  Pixel seeds use frame coordinates, so the bands of all ranks compose the rt_render frame bit for bit. */
+int rt_render_bands(rt_ctx* ctx, const rt_camera_params* camera, const rt_renderer_params* renderer,
+                    const rt_sky_params* sky, rt_rect tile, int32_t bandRows, int32_t firstBand, int32_t bandStride,
+                    rt_id fb);
+
 /* rt_render for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc).  It has no counterpart in the reference.  Same arguments, same pixels, ids and statistics as
  * rt_render with RT_OPT_TRAVERSAL = 0, but the wavefront workspace (path state, queues, hit records, redo lists)

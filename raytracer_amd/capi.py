@@ -62,7 +62,7 @@ EXPORTS = [
     "rt_material_update", "rt_material_destroy", "rt_object_create", "rt_object_destroy", "rt_scene_commit",
     "rt_camera_set_rays", "rt_framebuffer_create", "rt_framebuffer_wrap", "rt_framebuffer_destroy",
     "rt_framebuffer_read", "rt_framebuffer_write", "rt_framebuffer_enable_ids", "rt_framebuffer_read_ids",
-    "rt_render", "rt_render_noalloc", "rt_trace_rays", "rt_event_record", "rt_event_elapsed_ms", "rt_detmath_eval", "rt_version",
+    "rt_render", "rt_render_bands", "rt_render_noalloc", "rt_trace_rays", "rt_event_record", "rt_event_elapsed_ms", "rt_detmath_eval", "rt_version",
 ]
 
 OPT_TRAVERSAL, OPT_COUNTERS, OPT_ACCUMULATE_STATS, OPT_WF_CHUNK, OPT_WF_LANES, OPT_BUILDER = 1, 2, 3, 4, 5, 6
@@ -108,6 +108,8 @@ def lib():
         L.rt_render.argtypes = [C.c_void_p, C.POINTER(CameraParams), C.POINTER(RendererParams), C.POINTER(SkyParams),
                                 Rect, C.c_int32]
         L.rt_render_noalloc.argtypes = L.rt_render.argtypes
+        L.rt_render_bands.argtypes = [C.c_void_p, C.POINTER(CameraParams), C.POINTER(RendererParams), C.POINTER(SkyParams),
+                                      Rect, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
         L.rt_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         L.rt_event_record.argtypes = [C.c_void_p, C.c_int]
         L.rt_event_elapsed_ms.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
@@ -254,7 +256,9 @@ class Context:
         self.check(self.L.rt_framebuffer_read_ids(self.h, fb, a.ctypes.data))
         return a
 
-    def render(self, camera: Camera, st: RenderSettings, fb, rect=None, noalloc=False):
+    def render(self, camera: Camera, st: RenderSettings, fb, rect=None, noalloc=False, bands=None):
+        """rt_render; `bands` = (bandRows, firstBand, bandStride) renders only those row bands of `rect`
+        (rt_render_bands: one rank's share of a frame split over several GPUs)."""
         cam = CameraParams((C.c_float * 4)(*camera.Position, 1.0), (C.c_float * 4)(*camera.Rotation),
                            float(camera.exposureValue), camera.width, camera.height)
         rnd = RendererParams(int(st.bounceCount), float(st.maxDistance), float(st.aoIntensity),
@@ -263,6 +267,10 @@ class Context:
         sky = SkyParams((C.c_float * 4)(*st.lightDirection), (C.c_float * 4)(*st.lightColor),
                         (C.c_float * 4)(*st.skyColor))
         x0, y0, x1, y1 = rect if rect is not None else (0, 0, camera.width, camera.height)
+        if bands is not None:
+            self.check(self.L.rt_render_bands(self.h, C.byref(cam), C.byref(rnd), C.byref(sky), Rect(x0, y0, x1, y1),
+                                              int(bands[0]), int(bands[1]), int(bands[2]), fb))
+            return
         fn = self.L.rt_render_noalloc if noalloc else self.L.rt_render
         self.check(fn(self.h, C.byref(cam), C.byref(rnd), C.byref(sky), Rect(x0, y0, x1, y1), fb))
 

@@ -269,7 +269,7 @@ void launch_detmath(int op, const float* in, int n, float* out, hipStream_t stre
 
 extern "C" {
 
-const char* rt_version(void) { return "raytracer_amd 0.1 (gfx950)"; }
+const char* rt_version(void) { return "raytracer_amd 0.2.0 (gfx950)"; }
 
 const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_createError.c_str(); }
 
@@ -776,13 +776,19 @@ static int render_args(rt_ctx* c, const rt_camera_params* cam, const rt_renderer
     return RT_OK;
 }
 
-int rt_render(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* rnd, const rt_sky_params* sky, rt_rect tile,
-              rt_id fb)
+// rt_render and rt_render_bands: bandRows == 0 renders the whole tile
+static int render_impl(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* rnd, const rt_sky_params* sky,
+                       rt_rect tile, rt_id fb, int32_t bandRows, int32_t bandFirst, int32_t bandStride)
 {
     RT_BIND(c);
     rt::RenderArgs a;
-    const int rc = render_args(c, cam, rnd, sky, tile, fb, "rt_render", a);
+    const int rc = render_args(c, cam, rnd, sky, tile, fb, bandRows ? "rt_render_bands" : "rt_render", a);
     if (rc) return rc;
+    if (bandRows) {
+        if (bandRows < 0 || bandRows % 8 != 0 || bandFirst < 0 || bandStride < 1)
+            return fail(c, RT_ERR_INVALID, "rt_render_bands: bandRows must be a positive multiple of 8, firstBand >= 0, bandStride >= 1");
+        a.bandTileRows = bandRows / 8; a.bandFirst = bandFirst; a.bandStride = bandStride;
+    }
     const bool wavefront = c->optTraversal == 0 && rnd->bounceCount <= 200;
     if (c->optTraversal == 2 || (c->optTraversal == 0 && !wavefront)) {
         // persistent path kernel: one redo list over the tile's pixels (the wavefront pipeline keeps its own per lane)
@@ -802,7 +808,7 @@ int rt_render(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* 
     // mode 0: wavefront pipeline (the single persistent kernel, mode 2, remains for very deep paths:
     // the per-sample query count of the pipeline is a byte)
     if (wavefront) {
-        const size_t tiles = (size_t)((tile.x1 - tile.x0 + 7) / 8) * (size_t)((tile.y1 - tile.y0 + 7) / 8);
+        const size_t tiles = (size_t)((tile.x1 - tile.x0 + 7) / 8) * (size_t)rt::wf_tile_rows(a);
         const size_t perTile = 64 * (size_t)rnd->sampleCount;
         if (perTile >= (1ull << 31)) return fail(c, RT_ERR_INVALID, "sampleCount too large for one 8x8 tile of the wavefront workspace");
         if (tiles > 0) {
@@ -824,13 +830,34 @@ int rt_render(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* 
             RT_CHECK(c, hipEventRecord(c->evBegin, c->stream));
             rt::launch_render_wf(a, c->wf, c->numCUs, c->stream);
         }
-    } else {
+    } else if (!bandRows) {
         rt::launch_render(a, c->optTraversal == 1 ? 1 : 0, c->numCUs, c->stream);
+    } else { // the single-kernel modes take one launch per band; their work counters start at zero each time
+        rt::RenderArgs b = a;
+        b.bandTileRows = 0;
+        for (int32_t y = tile.y0 + bandFirst * bandRows; y < tile.y1; y += bandStride * bandRows) {
+            b.y0 = y; b.y1 = y + bandRows < tile.y1 ? y + bandRows : tile.y1;
+            if (y != tile.y0 + bandFirst * bandRows) RT_CHECK(c, hipMemsetAsync(c->dWork, 0, kWorkBytes, c->stream));
+            rt::launch_render(b, c->optTraversal == 1 ? 1 : 0, c->numCUs, c->stream);
+        }
     }
     RT_CHECK(c, hipGetLastError());
     RT_CHECK(c, hipEventRecord(c->evEnd, c->stream));
     c->renderedOnce = true;
     return RT_OK;
+}
+
+int rt_render(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* rnd, const rt_sky_params* sky, rt_rect tile,
+              rt_id fb)
+{
+    return render_impl(c, cam, rnd, sky, tile, fb, 0, 0, 1);
+}
+
+int rt_render_bands(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_params* rnd, const rt_sky_params* sky,
+                    rt_rect tile, int32_t bandRows, int32_t firstBand, int32_t bandStride, rt_id fb)
+{
+    if (bandRows == 0) return fail(c, RT_ERR_INVALID, "rt_render_bands: bandRows must be a positive multiple of 8");
+    return render_impl(c, cam, rnd, sky, tile, fb, bandRows, firstBand, bandStride);
 }
 
 // largest sample count per chunk whose workspace (wf_carve) fits the static array

@@ -53,6 +53,7 @@ struct WfLanes {
     hipEvent_t join[kWfMaxLanes] = {};
     WfBufs bufs[kWfMaxLanes] = {};
 };
+int wf_tile_rows(const RenderArgs& a);
 void launch_render_wf(const RenderArgs& a, const WfLanes& L, int numCUs, hipStream_t mainStream);
 void launch_trace_rays(const SceneView& s, const float4* rays, int n, uint4* out, unsigned long long* counters, int mode,
                        hipStream_t stream);

@@ -181,6 +181,10 @@ struct RenderArgs {
     uint32_t* redoCount;
     const uint32_t* pixelList;    // non-null: render these pixels instead of the tile
     const uint32_t* pixelCount;
+    // rt_render_bands (wavefront pipeline): the rectangle is cut into bands of bandTileRows rows of 8x8 tiles and only
+    // bands bandFirst, bandFirst + bandStride, ... are rendered; the pipeline's tile rows count through those bands
+    // only (tiles8Y = owned bands * bandTileRows).  bandTileRows == 0: the whole rectangle.
+    int32_t bandTileRows, bandFirst, bandStride;
 };
 
 } // namespace rt

@@ -781,8 +781,13 @@ __device__ __forceinline__ size_t wf_out_index(uint32_t pix, uint32_t sidx, uint
 __device__ __forceinline__ bool wf_pixel(const RenderArgs& a, const WfBufs& w, uint32_t pix, int& x, int& y)
 {
     const uint32_t tile = w.tileBegin + (pix >> 6) * w.tileStride, in = pix & 63u;
+    uint32_t row = tile / (uint32_t)a.tiles8X;
+    if (a.bandTileRows > 0) { // row counts through this call's bands only: band k of the call is band bandFirst + k * bandStride of the rectangle
+        const uint32_t k = row / (uint32_t)a.bandTileRows, in_band = row - k * (uint32_t)a.bandTileRows;
+        row = ((uint32_t)a.bandFirst + k * (uint32_t)a.bandStride) * (uint32_t)a.bandTileRows + in_band;
+    }
     x = a.x0 + (int)(tile % (uint32_t)a.tiles8X) * 8 + (int)(in & 7u);
-    y = a.y0 + (int)(tile / (uint32_t)a.tiles8X) * 8 + (int)(in >> 3);
+    y = a.y0 + (int)row * 8 + (int)(in >> 3);
     return x < a.x1 && y < a.y1;
 }
 
@@ -1384,6 +1389,17 @@ void launch_render(const RenderArgs& a, int mode, int numCUs, hipStream_t stream
     hipLaunchKernelGGL((render_kernel<2, 2>), dim3(256), dim3(256), 0, stream, c);
 }
 
+// rows of 8x8 tiles the wavefront pipeline walks for these arguments: the rectangle's, or those of the bands
+// this call owns (rt_render_bands)
+int wf_tile_rows(const RenderArgs& a)
+{
+    const int rows = (a.y1 - a.y0 + 7) / 8;
+    if (a.bandTileRows <= 0) return rows;
+    const int nBands = (rows + a.bandTileRows - 1) / a.bandTileRows;
+    const int owned = a.bandFirst < nBands ? (nBands - a.bandFirst + a.bandStride - 1) / a.bandStride : 0;
+    return owned * a.bandTileRows;
+}
+
 // Wavefront pipeline + redo launches.  The render rectangle is cut into chunks of whole 8x8 tiles;
 // chunk k runs on lane k % n (a lane = a HIP stream with its own workspace).  The lanes exist for
 // the tails: a level's trace launch ends with its slowest ray, traversed by one lane of one wave
@@ -1394,9 +1410,10 @@ void launch_render_wf(const RenderArgs& a, const WfLanes& L, int numCUs, hipStre
     if (a.x1 <= a.x0 || a.y1 <= a.y0) return;
     RenderArgs b = a;
     b.tiles8X = (a.x1 - a.x0 + 7) / 8;
-    b.tiles8Y = (a.y1 - a.y0 + 7) / 8;
+    b.tiles8Y = wf_tile_rows(a);
     b.pixelList = nullptr; b.pixelCount = nullptr;
     const uint32_t nTiles = (uint32_t)b.tiles8X * (uint32_t)b.tiles8Y;
+    if (nTiles == 0) return;
     const uint32_t spp = a.sampleCount;
     const uint32_t tilesPerChunk = L.tilesPerChunk;
     if (tilesPerChunk == 0 || L.n <= 0) return;

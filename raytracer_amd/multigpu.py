@@ -16,7 +16,8 @@ that they can be exercised on CPU with gloo:
 """
 from typing import List, Tuple
 
-BAND_ROWS = 64  # multiple of the 8-row tiles; a band of a 1080p x 16 spp frame is 2 M samples, enough for one wavefront chunk
+BAND_ROWS = 16  # multiple of the 8-row tiles.  A rank's bands run as one pass of the pipeline (rt_render_bands), so thin bands cost
+                # nothing and balance better: 4K over 8 ranks is 135 bands, 17 or 16 per rank (64-row bands: 5 or 4)
 
 
 def band_rects(width: int, height: int, rank: int, world: int, band_rows: int = BAND_ROWS) -> List[Tuple[int, int, int, int]]:
@@ -35,32 +36,59 @@ def frame_indices(first: int, count: int, rank: int, world: int) -> List[int]:
     return [f for f in range(first, first + count) if f % world == rank]
 
 
+def band_layout(height: int, world: int, band_rows: int = BAND_ROWS):
+    """(bands in the frame, bands per rank's packet, rows of the padded frame): the padded frame holds
+    per_rank * world whole bands, so that band b = k * world + r sits at [k, r] of a 5-D view."""
+    nb = (height + band_rows - 1) // band_rows
+    per_rank = (nb + world - 1) // world
+    return nb, per_rank, per_rank * world * band_rows
+
+
+class TileCompositor:
+    """Composite of one frame rendered as interleaved row bands (rank r owns bands r, r + world, ...;
+    rt_render_bands with (firstBand, bandStride) = (rank, world)).  The frame lives in a tensor padded to a
+    whole number of band rounds, `frame` is its first `height` rows (wrap that as the framebuffer):
+
+        pack    one strided copy: the rank's bands -> a contiguous packet (1/world of a frame)
+        gather  one all_gather of equal-sized packets into [world, per_rank, band_rows, W, 4]
+        unpack  one strided copy: gathered.permute(1, 0, ...) -> the padded frame
+
+    No per-band Python loop, no allocation per frame.  Seeds use frame coordinates, so the composite is
+    bit-identical to the single-GPU frame."""
+
+    def __init__(self, torch, dist, width, height, rank, world, device=None, band_rows: int = BAND_ROWS, dtype=None):
+        self.dist, self.rank, self.world, self.band_rows = dist, rank, world, band_rows
+        self.width, self.height = width, height
+        self.nb, self.per_rank, rows = band_layout(height, world, band_rows)
+        dtype = dtype or torch.float32
+        self.padded = torch.zeros((rows, width, 4), dtype=dtype, device=device)
+        self.frame = self.padded[:height]
+        self.view = self.padded.view(self.per_rank, world, band_rows, width, 4)
+        self.packet = torch.empty((self.per_rank, band_rows, width, 4), dtype=dtype, device=device)
+        self.gathered = torch.empty((world, self.per_rank, band_rows, width, 4), dtype=dtype, device=device)
+
+    def composite(self):
+        """All ranks call this after rendering their bands into `frame`; on return `frame` is complete."""
+        if self.world == 1:
+            return self.frame
+        self.packet.copy_(self.view[:, self.rank])
+        if self.dist.get_backend() == "nccl":   # RCCL: straight into the contiguous [world, ...] tensor
+            self.dist.all_gather_into_tensor(self.gathered, self.packet)
+        else:
+            self.dist.all_gather(list(self.gathered.unbind(0)), self.packet)
+        self.view.copy_(self.gathered.permute(1, 0, 2, 3, 4))
+        return self.frame
+
+
 def composite_tiles(dist, local_fb, width, height, rank, world, band_rows: int = BAND_ROWS):
-    """Composite of one frame rendered as interleaved row bands: every rank packs the bands it owns into one
-    contiguous tensor, one all_gather moves them (1/world of a frame per rank instead of a whole frame), and
-    each rank unpacks every owner's bands into place.  `local_fb` is a torch tensor [H, W, 4]; rows this rank
-    does not own are ignored on input and filled on output.  Ranks that own one band fewer (or a short last
-    band) pad their packet with zeros so that the collective stays a plain equal-sized all_gather."""
+    """One-shot form of TileCompositor for a plain [H, W, 4] tensor (copies in and out of a padded frame)."""
     import torch
 
     if world == 1:
         return local_fb
-    nb = (height + band_rows - 1) // band_rows
-    per_rank = (nb + world - 1) // world                      # bands in a packet
-    def owned(r):
-        return list(range(r, nb, world))
-    packet = torch.zeros((per_rank * band_rows, width, 4), dtype=local_fb.dtype, device=local_fb.device)
-    for k, b in enumerate(owned(rank)):
-        y0, y1 = b * band_rows, min(height, (b + 1) * band_rows)
-        packet[k * band_rows:k * band_rows + (y1 - y0)] = local_fb[y0:y1]
-    parts = [torch.empty_like(packet) for _ in range(world)]
-    dist.all_gather(parts, packet)
-    out = torch.empty_like(local_fb)
-    for r in range(world):
-        for k, b in enumerate(owned(r)):
-            y0, y1 = b * band_rows, min(height, (b + 1) * band_rows)
-            out[y0:y1] = parts[r][k * band_rows:k * band_rows + (y1 - y0)]
-    return out
+    tc = TileCompositor(torch, dist, width, height, rank, world, local_fb.device, band_rows, local_fb.dtype)
+    tc.frame.copy_(local_fb)
+    return tc.composite().clone()
 
 
 def reduce_frames(dist, local_sum, world, dst=0):

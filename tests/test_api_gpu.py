@@ -189,3 +189,40 @@ def test_every_pixel_flagged_in_every_chunk(ctx, lanes, chunk):
     finally:
         ctx.set_option(capi.OPT_WF_LANES, 0)
         ctx.set_option(capi.OPT_WF_CHUNK, 0)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["bvh-wavefront", "brute", "bvh-persistent"])
+def test_render_bands_compose_the_frame(ctx, mode):
+    """rt_render_bands: the interleaved row bands of n callers (one pass of the pipeline each) compose the
+    rt_render frame bit for bit -- ragged last band, a sub-rectangle, more ranks than bands, progressive blend."""
+    sc, cam = small_scene()
+    cam.setWidth(150); cam.setHeight(117); cam.calcRays()
+    st = RenderSettings(bounceCount=3, sampleCount=3, frameCount=4, progressiveFrameCount=2)
+    flat = sc.flatten()
+    prev = np.random.default_rng(2).random((cam.height, cam.width, 4)).astype(np.float32)
+    ctx.set_option(capi.OPT_TRAVERSAL, mode)
+    ctx.upload_scene(flat)
+    ctx.set_camera_rays(cam.preTransformRays)
+    fb = ctx.framebuffer(cam.width, cam.height, ids=True)
+    fb2 = ctx.framebuffer(cam.width, cam.height, ids=True)
+    for rect in (None, (11, 5, 140, 101)):
+        ctx.write(fb, prev); ctx.write(fb2, prev)
+        ctx.render(cam, st, fb, rect)
+        want, wid, rays = ctx.read(fb, cam.width, cam.height), ctx.read_ids(fb, cam.width, cam.height), ctx.stats().rays
+        for band_rows, world in ((16, 3), (8, 5), (64, 4)):
+            ctx.write(fb2, prev)
+            total = 0
+            for r in range(world):
+                ctx.render(cam, st, fb2, rect, bands=(band_rows, r, world))
+                total += ctx.stats().rays
+            assert np.array_equal(ctx.read(fb2, cam.width, cam.height), want), (rect, band_rows, world)
+            got_ids = ctx.read_ids(fb2, cam.width, cam.height)
+            x0, y0, x1, y1 = rect or (0, 0, cam.width, cam.height)
+            assert np.array_equal(got_ids[y0:y1, x0:x1], wid[y0:y1, x0:x1]) and total == rays
+    ref, _, _ = orc.render(flat, cam, st, prev=prev)
+    ctx.write(fb, prev)
+    ctx.render(cam, st, fb)
+    assert np.array_equal(ctx.read(fb, cam.width, cam.height), ref)
+    with pytest.raises(capi.RtError, match="multiple of 8"):
+        ctx.render(cam, st, fb, None, bands=(12, 0, 2))
+    ctx.framebuffer_destroy(fb); ctx.framebuffer_destroy(fb2)

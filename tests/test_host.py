@@ -147,6 +147,12 @@ for r in multigpu.band_rects(64, 44, rank, world, band_rows=8):
     fb2[r[1]:r[3]] = full[r[1]:r[3]]
 comp2 = multigpu.composite_tiles(dist, torch.from_numpy(fb2[:44].copy()), 64, 44, rank, world, band_rows=8).numpy()
 assert np.array_equal(comp2, full[:44]), "ragged tile composite differs"
+# the compositor bench.py uses: the frame lives in a padded tensor, one strided copy each way, no per-band loop
+tc = multigpu.TileCompositor(torch, dist, 64, 44, rank, world, band_rows=8)
+assert tc.padded.shape[0] == 48 and tc.frame.shape[0] == 44 and tc.per_rank == 3
+for b in range(rank, tc.nb, world):   # what rt_render_bands(firstBand = rank, bandStride = world) fills
+    tc.frame[b * 8:min(44, (b + 1) * 8)] = torch.from_numpy(full[b * 8:min(44, (b + 1) * 8)])
+assert np.array_equal(tc.composite().numpy(), full[:44]), "TileCompositor differs"
 # frames: progressive split + reduce == serial sum within 1e-6
 frames = list(range(0, 6))
 local = torch.zeros((48, 64, 4))
