@@ -36,7 +36,8 @@ enum rt_status {
 
 /* processor/GPU/GPURaytracer.hpp:60-69 (CameraParams; the ray texture is set separately) */
 typedef struct {
-    float origin[4];
+    float origin[4];   /* x, y, z, w; w must be 1 (the reference always passes glm::vec4(position, 1.0f), GPURaytracer.cu:29): the
+                          kernels transform the origin as a point and do not read w; rt_render rejects any other value */
     float rotation[4]; /* quaternion x,y,z,w */
     float exposure;
     int32_t width;
@@ -94,7 +95,7 @@ enum rt_option {
     RT_OPT_COUNTERS = 2,  /* reserved */
     RT_OPT_ACCUMULATE_STATS = 3, /* 1 = rt_render no longer zeroes the counters; setting it zeroes them once */
     RT_OPT_WF_CHUNK = 4,  /* samples in flight per chunk of the wavefront pipeline (0 = default, 64 Mi); the
-                             workspace holds ~113 bytes per sample and lane */
+                             workspace holds ~185 bytes per sample and lane (64 Mi samples x 3 lanes = 36 GB) */
     RT_OPT_WF_LANES = 5,  /* chunks in flight at once, each on its own HIP stream (0 = default: one per chunk of the
                              frame, at most 3; 1..4) */
     RT_OPT_BUILDER = 6    /* acceleration structure built by rt_scene_commit: 0 = PLOC (default: slower commit, faster
@@ -179,12 +180,14 @@ int rt_render_noalloc(rt_ctx* ctx, const rt_camera_params* camera, const rt_rend
  * (object, mesh, triangle, float bits of t; all 0xFFFFFFFF on miss).  Host pointers. */
 int rt_trace_rays(rt_ctx* ctx, const float* rays, int32_t nRays, uint32_t* out);
 
-/* HIP-event timing on the context stream: record into slot 0..15, elapsed between two slots */
+/* HIP-event timing on the context stream: record into slot 0..13, elapsed between two slots
+ * (slots 14 and 15 belong to the library: they time rt_scene_commit) */
 int rt_event_record(rt_ctx* ctx, int slot);
 int rt_event_elapsed_ms(rt_ctx* ctx, int slot_begin, int slot_end, float* ms);
 
 /* test tap: evaluate the pinned device math on n host floats.
- * op: 0 log, 1 cos, 2 exp, 3 pow(x,5), 4 pow(x,1000), 5 rsqrt, 6 random_value(seed bits) */
+ * op: 0 log, 1 cos, 2 exp, 3 pow(x,5), 4 pow(x,1000), 5 rsqrt, 6 random_value(seed bits), 7 byte/255 (input = byte as
+ * integer bits), 8 exhaustive check of the 32-bit -> [0,1] conversion (input = high 16 bits; output = mismatch count) */
 int rt_detmath_eval(rt_ctx* ctx, int op, const float* in, int32_t n, float* out);
 
 const char* rt_version(void);

@@ -4,6 +4,8 @@
 #include "rt_commit.h"
 #include "rt_detmath.h"
 
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -84,6 +86,7 @@ struct rt_ctx {
     int numCUs = 256;
     uint32_t* dWork = nullptr;      // 8 tile counters (32 words apart) + redo count at word 256
     uint32_t* dRedoList = nullptr; size_t redoCap = 0;
+    float bandRel = 2e-4f;          // tie band of the committed scene, see band_rel_of
     void* scratchPtr = nullptr;     // this device's copy of the static workspace (rt_render_noalloc)
 };
 
@@ -136,6 +139,33 @@ int check_material_desc(rt_ctx* c, const rt_material_desc* d)
     for (int i = 0; i < 4; i++)
         if (t[i] != -1 && !valid(c->textures, t[i])) return fail(c, RT_ERR_INVALID, "material references an invalid texture handle");
     return RT_OK;
+}
+
+// Relative width of the tie band for a set of instances (exactness).  The BVH answer equals
+// the reference's in-order answer unless another object has a hit within rounding distance of the winner; that
+// distance is set by how far the reference's object-space cull (origin and direction through the host's float
+// inverse, GPURaytracer.cu:267-315) can disagree with the world-space triangle test: up to
+// cond(model) * 2^-23 * (extent + |translation|), and 1 / cos(incidence) times that for a grazing ray.  The band is
+// rel * (t + max |coordinate|); rel = 2e-4 covers cond * 1 / cos up to ~1700 (cond = 1 for any rigid or uniformly
+// scaled instance); beyond that it grows with the worst instance: 64 * cond * 2^-23.  A singular or non-finite
+// matrix makes it infinite: every ray that hits two objects then takes the exact in-order emulation.
+float band_rel_of(const float* model16, const float* inv16, int n)
+{
+    double worst = 1.0;
+    for (int i = 0; i < n; i++) {
+        const float* m = model16 + 16 * (size_t)i;
+        const float* v = inv16 + 16 * (size_t)i;
+        double nm = 0.0, nv = 0.0;
+        for (int r = 0; r < 3; r++) { // infinity norms of the 3x3 parts (column-major storage)
+            nm = std::max(nm, (double)std::fabs(m[r]) + std::fabs(m[4 + r]) + std::fabs(m[8 + r]));
+            nv = std::max(nv, (double)std::fabs(v[r]) + std::fabs(v[4 + r]) + std::fabs(v[8 + r]));
+        }
+        const double cond = nm * nv;
+        if (!(cond < 1e30)) return INFINITY;   // also NaN
+        worst = std::max(worst, cond);
+    }
+    const double rel = 64.0 * worst * 1.1920929e-07;
+    return (float)std::max(2e-4, rel);
 }
 
 // device table of the live textures (index = handle); the stream must be idle
@@ -219,6 +249,7 @@ rt::SceneView scene_view(const rt_ctx* c)
     s.nTris = c->built.nTris; s.nObjects = c->nObjects;
     s.rootIsValid = c->built.nTris > 0 ? 1 : 0;
     s.sceneMaxAbs = c->built.sceneMaxAbs;
+    s.bandRel = c->bandRel;
     return s;
 }
 
@@ -643,6 +674,7 @@ int rt_scene_commit(rt_ctx* c, const rt_id* objects, const float* model16, const
     hipFree(dSegs); hipFree(dXf);
     if (!ok) { rt::free_scene(c->built); return fail(c, RT_ERR_HIP, "scene build failed: " + err); }
     hipEventElapsedTime(&c->commitMs, c->slots[14], c->slots[15]);
+    c->bandRel = band_rel_of(model16, invModel16, n);
     c->committed = true;
     return RT_OK;
 }
@@ -760,6 +792,7 @@ static int render_args(rt_ctx* c, const rt_camera_params* cam, const rt_renderer
     if (tile.x0 < 0 || tile.y0 < 0 || tile.x1 > f.w || tile.y1 > f.h || tile.x0 > tile.x1 || tile.y0 > tile.y1)
         return fail(c, RT_ERR_INVALID, "tile outside the framebuffer");
     if (rnd->sampleCount == 0) return fail(c, RT_ERR_INVALID, "sampleCount must be at least 1");
+    if (cam->origin[3] != 1.0f) return fail(c, RT_ERR_INVALID, "camera origin[3] must be 1 (a point, GPURaytracer.cu:29)");
 
     memset(&a, 0, sizeof(a));
     a.scene = scene_view(c);

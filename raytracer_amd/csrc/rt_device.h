@@ -103,6 +103,7 @@ struct SceneView {
     uint32_t nObjects;
     int32_t rootIsValid;       // 0 when the scene holds no triangle
     float sceneMaxAbs;         // max |coordinate| over all world-space vertices
+    float bandRel;             // relative width of the tie band (rt_trace.h band_of): 2e-4, or wider for ill-conditioned instances
 };
 
 // ---- wavefront pipeline (rt_render.hip, "wf_" kernels) ----

@@ -370,7 +370,9 @@ struct HotStackT {
 using HotStack = HotStackT<kLdsStack>;
 
 // Band inside which a hit on a different object triggers the exact in-order emulation.
-__device__ __forceinline__ float band_of(float t, float rayScale) { return 2e-4f * (t + rayScale); }
+// rel = SceneView::bandRel: 2e-4 for ordinary scenes, widened by rt_scene_commit to cover the rounding of the
+// object-space cull against the world-space triangles when a model matrix is badly conditioned.
+__device__ __forceinline__ float band_of(float t, float rayScale, float rel) { return rel * (t + rayScale); }
 
 // One node visit of a lane: test the four children, sort the hit ones front to back (sorting
 // network on (distance, child) pairs), enter the nearest, push the others farthest first; pop when
@@ -532,7 +534,7 @@ __device__ __forceinline__ bool trace_band_table(const SceneView& s, Ray& ray, f
     const float rayScale = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ray.ox), __builtin_fabsf(ray.oy)),
                                            __builtin_fmaxf(__builtin_fabsf(ray.oz), s.sceneMaxAbs));
     const float m0 = ray.maxDist;
-    const float limit = __builtin_fminf(tBest + band_of(tBest, rayScale), m0);
+    const float limit = __builtin_fminf(tBest + band_of(tBest, rayScale, s.bandRel), m0);
     BandEntry e0, e1;
     e0.obj = e1.obj = kNoHit;
     e0.h.t = e1.h.t = FLT_MAX; e0.h.gid = e1.h.gid = kNoHit;
@@ -611,11 +613,11 @@ __device__ __forceinline__ Hit trace_bvh(const SceneView& s, Ray& ray, Stack& st
         } else {
             otherT = __builtin_fminf(otherT, t);
         }
-        return __builtin_fminf(m0, best.t + band_of(best.t, rayScale));
+        return __builtin_fminf(m0, best.t + band_of(best.t, rayScale, s.bandRel));
     });
 
     if (best.gid == kNoHit) return best;
-    const float limit = best.t + band_of(best.t, rayScale);
+    const float limit = best.t + band_of(best.t, rayScale, s.bandRel);
     if (otherT <= limit) {
         slowPath++;
         return trace_bvh_exact(s, ray, q, br, __builtin_fminf(limit, m0), stack, cnt);
@@ -638,7 +640,7 @@ struct Trav {
     int32_t node;
     uint32_t triFirst, triCount, triBase;
     int sp;
-    float bound, m0, rayScale;
+    float bound, m0, rayScale, bandRel;
     Hit best;
     uint32_t bestObj;
     float otherT;
@@ -653,6 +655,7 @@ __device__ __forceinline__ void trav_init(Trav& T, const SceneView& s, const Ray
     T.br = make_box_ray(ray, s.sceneMaxAbs);
     T.rayScale = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ray.ox), __builtin_fabsf(ray.oy)),
                                  __builtin_fmaxf(__builtin_fabsf(ray.oz), s.sceneMaxAbs));
+    T.bandRel = s.bandRel;
     T.m0 = ray.maxDist; T.bound = ray.maxDist;
     T.best.t = FLT_MAX; T.best.gid = kNoHit; T.best.b0 = T.best.b1 = T.best.b2 = 0.0f;
     T.bestObj = kNoHit; T.otherT = FLT_MAX;
@@ -699,7 +702,7 @@ __device__ __forceinline__ void trav_test_triangle(Trav& T, const float4& A, con
         }
         if (better) {
             T.best.t = t; T.best.b0 = b0; T.best.b1 = b1; T.best.b2 = b2; T.best.gid = gid;
-            T.bound = __builtin_fminf(T.m0, t + band_of(t, T.rayScale));
+            T.bound = __builtin_fminf(T.m0, t + band_of(t, T.rayScale, T.bandRel));
         }
     }
 }
@@ -771,7 +774,7 @@ __device__ __forceinline__ void trav_burst(Trav& T, const SceneView& s, const Ra
 __device__ __forceinline__ Hit trav_result(const Trav& T, Ray& ray, bool& danger)
 {
     if (T.best.gid != kNoHit) {
-        const float limit = T.best.t + band_of(T.best.t, T.rayScale);
+        const float limit = T.best.t + band_of(T.best.t, T.rayScale, T.bandRel);
         if (T.otherT <= limit) danger = true;
         ray.maxDist = T.best.t;
     }

@@ -172,10 +172,41 @@ def _look_quat(pitch_deg, yaw_deg=0.0):
     return tuple(np.float32(v) for v in q)
 
 
+_REF_ASSETS = None
+
+
+def reference_assets():
+    """The reference's own model files flattened by tests/golden/make_assets.py (murasama.fbx, model.dae, four 8-bit
+    gray maps), or None when the fixture is absent.  The file travels with the repository, so the GPU box renders
+    the real geometry without /root/reference."""
+    global _REF_ASSETS
+    if _REF_ASSETS is None:
+        import os
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ref_assets.npz")
+        _REF_ASSETS = dict(np.load(path)) if os.path.exists(path) else False
+    return _REF_ASSETS or None
+
+
+def workload_label(name):
+    """bench.py's config.workload string: says whether the reference's geometry or a stand-in is rendered."""
+    real = reference_assets() is not None
+    return {
+        "c3": "C3 pbrsword: " + ("reference geometry (murasama.fbx flattened, 8 972 tris) + its roughness / metallic maps, procedural albedo + normal"
+                                 if real else "synthetic stand-in mesh and maps") + ", 2048^2 x 4 maps",
+        "c4": "C4 331 x lowpolypbrtrash: " + ("reference geometry (model.dae flattened, 6 meshes, 3 024 tris) x 331 = 1 000 944 tris, metalmaterial roughness / metalness maps"
+                                                if real else "synthetic stand-in meshes") + ", 2 PBR material sets x 4 maps",
+        "c5": "C5 stress: 10 M-triangle terrain + 10 000 tessellated spheres (13.5 M tris)",
+    }.get(name, name)
+
+
 def sword_mesh():
-    """Stand-in for res/pbrsword/source/murasama.fbx (4 671 control points, ~8 972 triangles after
+    """The reference's res/pbrsword/source/murasama.fbx as flattened into the fixture (8 972 triangles); without the
+    fixture, a stand-in for res/pbrsword/source/murasama.fbx (4 671 control points, ~8 972 triangles after
     fan triangulation; the FBX cannot travel to the GPU box): a katana-like blade, guard and
     wrapped handle with about the same triangle count and extents (x in [-2.5, 2.5])."""
+    ra = reference_assets()
+    if ra is not None:
+        return Mesh(ra["sword_pos"].reshape(-1), ra["sword_idx"].reshape(-1), ra["sword_uv"].reshape(-1), ra["sword_nrm"].reshape(-1))
     parts = [
         ellipsoid_mesh(1.9, 0.17, 0.035, 96, 24, (0.6, 0.0, 0.0)),     # blade   4416
         ellipsoid_mesh(0.06, 0.26, 0.2, 32, 12, (-1.3, 0.0, 0.0)),     # guard    704
@@ -187,40 +218,67 @@ def sword_mesh():
 
 
 def config3(width=3840, height=2160, spp=64, depth=4, tex_size=2048):
-    """C3 (BASELINE.json configs[2]): PBR sword stand-in with albedo / normal / roughness / metal 2048^2
-    textures, 3840x2160, 64 spp.  Geometry and textures are synthetic (the FBX and its textures are
-    reference assets that do not travel; the real normal map is a missing blob anyway)."""
+    """C3 (BASELINE.json configs[2]): the PBR sword with albedo / normal / roughness / metal 2048^2 textures,
+    3840x2160, 64 spp.  With tests/golden/ref_assets.npz the geometry is the reference's murasama.fbx and the
+    roughness / metallic maps are its own; albedo (16-bit, 3.4 MB: not in the fixture) and the normal map
+    (missing from the reference checkout) are procedural.  Without the fixture everything is a stand-in."""
     width, height, spp, depth = width or 3840, height or 2160, spp or 64, depth or 4
     scene = Scene()
     steel = Material("Steel", (0.8, 0.8, 0.85, 1.0), 0.3, 1.0)
     steel.setAlbedoTexture(Texture(procedural_texture(tex_size, 11, "albedo")))
     steel.setNormalTexture(Texture(procedural_texture(tex_size, 12, "normal")))
-    steel.setRoughnessTexture(Texture(procedural_texture(tex_size, 13, "scalar")[..., 0]))
-    steel.setMetalTexture(Texture(procedural_texture(tex_size, 14, "scalar")[..., 0]))
+    ra = reference_assets()
+    if ra is not None and tex_size == 2048:
+        steel.setRoughnessTexture(Texture(ra["sword_roughness"]))
+        steel.setMetalTexture(Texture(ra["sword_metallic"]))
+    else:
+        steel.setRoughnessTexture(Texture(procedural_texture(tex_size, 13, "scalar")[..., 0]))
+        steel.setMetalTexture(Texture(procedural_texture(tex_size, 14, "scalar")[..., 0]))
     stone = Material("Stone", (0.5, 0.48, 0.45, 1.0), 0.8, 0.0)
-    sword = MeshObject([(sword_mesh(), 0)], [steel], position=(0.0, 0.45, 0.0), rotation=_quat_axis_angle((0, 0, 1), 12.0))
+    if ra is not None:
+        # the FBX's blade is broad in its z: stood on edge (z -> y) and tilted, broadside to a close camera.  A 13:1 object
+        # cannot fill 30 % of a 16:9 frame (SURVEY 8d asks for it): sword 6 %, sword + plinth 47 % of the primary hits
+        rot = tuple(np.float32(v) for v in _quat_mul(_quat_axis_angle((0, 0, 1), 20.0), _quat_axis_angle((1, 0, 0), -90.0)))
+        sword = MeshObject([(sword_mesh(), 0)], [steel], position=(0.0, 0.9, 0.0), rotation=rot)
+        cam = Camera((0.0, 1.3, 3.3), _look_quat(-12.0), 45.0, 1.0)
+    else:
+        sword = MeshObject([(sword_mesh(), 0)], [steel], position=(0.0, 0.45, 0.0), rotation=_quat_axis_angle((0, 0, 1), 12.0))
+        cam = Camera((0.0, 1.4, 5.2), _look_quat(-12.0), 45.0, 1.0)
     plinth = MeshObject([(merge_meshes([box_mesh((-3.2, -0.3, -1.2), (3.2, 0.0, 1.2))]), 0)], [stone])
     scene.addToScene("sword", sword)
     scene.addToScene("plinth", plinth)
-    cam = Camera((0.0, 1.4, 5.2), _look_quat(-12.0), 45.0, 1.0)
     cam.setWidth(width); cam.setHeight(height); cam.calcRays()
     return scene, cam, RenderSettings(bounceCount=depth, sampleCount=spp)
 
 
 def trashcan_meshes():
-    """Stand-in for res/lowpolypbrtrash/source/model.dae: 6 meshes with the DAE's triangle counts
-    (640 + 896 + 4 x 372 = 3 024)."""
+    """res/lowpolypbrtrash/source/model.dae as flattened into the fixture: 6 meshes, 640 + 896 + 4 x 372 = 3 024
+    triangles, Z up, node transforms ignored as in the reference (CustomModel.cpp:135-145); returns (meshes,
+    material slot per mesh, up-axis fix).  Without the fixture: stand-ins with the same counts, Y up."""
+    ra = reference_assets()
+    if ra is not None:
+        meshes = [Mesh(ra[f"trash{k}_pos"].reshape(-1), ra[f"trash{k}_idx"].reshape(-1), ra[f"trash{k}_uv"].reshape(-1),
+                       ra[f"trash{k}_nrm"].reshape(-1)) for k in range(6)]
+        return meshes, [int(v) for v in ra["trash_material"]], (-0.70710678, 0.0, 0.0, 0.70710678)
     body = merge_meshes([ellipsoid_mesh(0.45, 0.6, 0.45, 32, 11, (0, 0.6, 0))])        # 640
     lid = merge_meshes([ellipsoid_mesh(0.5, 0.12, 0.5, 32, 15, (0, 1.25, 0))])          # 896
     wheels = [merge_meshes([ellipsoid_mesh(0.12, 0.12, 0.06, 31, 7, (sx * 0.35, 0.12, sz * 0.42))])
               for sx in (-1, 1) for sz in (-1, 1)]                                        # 4 x 372
-    return [body, lid] + wheels
+    return [body, lid] + wheels, [0, 0, 1, 1, 1, 1], (0.0, 0.0, 0.0, 1.0)
+
+
+def _quat_mul(a, b):
+    x1, y1, z1, w1 = a; x2, y2, z2, w2 = b
+    return (w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+            w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2)
 
 
 def config4(width=3840, height=2160, spp=4, depth=4, tex_size=2048, instances=331):
     """C4 (BASELINE.json configs[3]): 331 instances of a 3 024-triangle, 6-mesh model = 1 000 944
-    triangles on a jittered grid (LCG seed 1), two PBR material sets with four textures each, 4K.
-    Synthetic stand-in for lowpolypbrtrash + metalmaterial (reference assets do not travel)."""
+    triangles on a jittered grid (LCG seed 1), PBR material sets with four textures each, 4K.
+    With tests/golden/ref_assets.npz the model is the reference's lowpolypbrtrash model.dae (stood upright:
+    it is Z up) and the second material set carries metalmaterial's roughness / metalness maps; albedo and
+    normal maps are procedural (the reference's are JPEG / missing).  Without the fixture: stand-in meshes."""
     width, height, spp, depth = width or 3840, height or 2160, spp or 4, depth or 4
     scene = Scene()
     mats = []
@@ -232,7 +290,11 @@ def config4(width=3840, height=2160, spp=4, depth=4, tex_size=2048, instances=33
         m.setMetalTexture(Texture(procedural_texture(tex_size // 2, 24 + 10 * k, "scalar")[..., 0]))
         mats.append(m)
     ground = Material("Floor", (0.4, 0.4, 0.42, 1.0), 0.9, 0.0)
-    meshes = trashcan_meshes()
+    meshes, slots, upright = trashcan_meshes()
+    ra = reference_assets()
+    if ra is not None and tex_size == 2048:
+        mats[1].setRoughnessTexture(Texture(ra["metal_roughness"]))
+        mats[1].setMetalTexture(Texture(ra["metal_metalness"]))
     side = int(np.ceil(np.sqrt(instances)))
     state = 1
     def lcg():
@@ -242,10 +304,10 @@ def config4(width=3840, height=2160, spp=4, depth=4, tex_size=2048, instances=33
     for i in range(instances):
         gx, gz = i % side, i // side
         pos = ((gx - side / 2) * 1.6 + (lcg() - 0.5) * 0.5, 0.0, (gz - side / 2) * 1.6 + (lcg() - 0.5) * 0.5)
-        rot = _quat_axis_angle((0, 1, 0), lcg() * 360.0)
-        s = 0.85 + 0.3 * lcg()
+        rot = tuple(np.float32(v) for v in _quat_mul(_quat_axis_angle((0, 1, 0), lcg() * 360.0), upright))
+        s = (0.85 + 0.3 * lcg()) * (1.5 if ra is not None else 1.0)   # the DAE's pile is ~0.55 x 1.3 x 0.6
         k = i % 2
-        o = MeshObject([(m, 0 if j < 2 else 1) for j, m in enumerate(meshes)], [mats[k], mats[1 - k]], pos, rot, (s, s, s))
+        o = MeshObject([(m, slots[j] % 2) for j, m in enumerate(meshes)], [mats[k], mats[1 - k]], pos, rot, (s, s, s))
         scene.addToScene(f"can{i}", o)
     ext = side * 0.8 + 2
     scene.addToScene("floor", MeshObject([(merge_meshes([box_mesh((-ext, -0.25, -ext), (ext, 0.0, ext))]), 0)], [ground]))

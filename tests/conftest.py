@@ -14,6 +14,14 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def ctx():
+    # torch first: its wheel bundles its own HIP runtime, and a process that has already initialised the system's
+    # (through librt_amd.so) cannot initialise a second one ("No HIP GPUs are available").  Loaded in this order,
+    # librt_amd.so binds to the runtime torch brought, as in bench.py, and device pointers are shared.
+    try:
+        import torch
+        torch.cuda.is_available()
+    except ImportError:
+        pass
     from raytracer_amd import capi
     c = capi.Context(0)
     yield c

@@ -145,15 +145,19 @@ def random_rays(rng, n, extent=4.0):
     return r
 
 
-def adversarial_rays(flat, rng, n):
-    """Rays aimed exactly at world-space vertices and edge midpoints, and axis-parallel rays."""
+def _world_vertices(flat):
     verts = []
     for o in flat.objects:
         m = np.asarray(o["model"], np.float64).reshape(4, 4).T
         for mid in o["meshIds"]:
             v = flat.meshes[mid].vertices.reshape(-1, 3).astype(np.float64)
             verts.append((v @ m[:3, :3].T + m[:3, 3]).astype(np.float32))
-    verts = np.concatenate(verts)
+    return np.concatenate(verts)
+
+
+def adversarial_rays(flat, rng, n):
+    """Rays aimed exactly at world-space vertices and edge midpoints, and axis-parallel rays."""
+    verts = _world_vertices(flat)
     a = verts[rng.integers(0, len(verts), n)]
     b = verts[rng.integers(0, len(verts), n)]
     tgt = np.where(rng.random((n, 1)) < 0.5, a, (0.5 * (a + b)).astype(np.float32))
@@ -218,6 +222,102 @@ def test_touching_and_duplicate_objects_take_the_exact_path(ctx):
     ctx.upload_scene(flat)
     got = ctx.trace_rays(rays)
     assert np.array_equal(got, ref)
+
+
+def _check_frames_and_rays(ctx, sc, cams, rng, ray_extent, ray_center, n_rays=30000, spp=2, depth=4):
+    flat = sc.flatten()
+    for cam in cams:
+        st = RenderSettings(bounceCount=depth, sampleCount=spp, maxDistance=1e6)
+        compare_modes(ctx, flat, cam, st)
+    # random rays through the neighbourhood of ray_center, and rays from around it aimed at vertices / edge midpoints
+    center = np.asarray(ray_center, np.float32)
+    a = random_rays(rng, n_rays, ray_extent)
+    a[:, :3] += center
+    b = np.zeros((n_rays, 8), np.float32)
+    o = (center + rng.uniform(-2 * ray_extent, 2 * ray_extent, (n_rays, 3))).astype(np.float32)
+    verts = _world_vertices(flat)
+    tgt = verts[rng.integers(0, len(verts), n_rays)]
+    d = tgt - o
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)
+    b[:, :3] = o; b[:, 4:7] = d.astype(np.float32)
+    rays = np.concatenate([a, b])
+    rays[:, 3] = 1e6
+    ref = orc.trace_rays(flat, rays)
+    for mode, builder in ((1, 0), (0, 0), (0, 1)):
+        ctx.set_option(capi.OPT_TRAVERSAL, mode)
+        ctx.set_option(capi.OPT_BUILDER, builder)
+        try:
+            ctx.upload_scene(flat)
+            got = ctx.trace_rays(rays)
+        finally:
+            ctx.set_option(capi.OPT_BUILDER, 0)
+        bad = np.nonzero((got != ref).any(axis=1))[0]
+        assert bad.size == 0, (mode, builder, bad[:5], got[bad[:5]], ref[bad[:5]])
+    return ref
+
+
+def _cam(pos, quat, w=112, h=80, fov=45.0):
+    cam = Camera(pos, quat, fov, 1.0)
+    cam.setWidth(w); cam.setHeight(h); cam.calcRays()
+    return cam
+
+
+def test_extreme_scales_in_one_scene(ctx):
+    """Non-uniform scales from 1e-3 to 1e3 inside one scene, rotated: cond(model) up to 1e6, so the object-space
+    cull (GPURaytracer.cu:267-315, through the host's float inverse) and the world-space triangle test round very
+    differently.  rt_scene_commit widens the tie band with the worst cond (band_rel_of), which sends every
+    doubtful ray through the exact in-order emulation; result: same bits as brute force and as the oracle."""
+    rng = np.random.default_rng(21)
+    m = [Material("a", (0.7, 0.3, 0.3, 1), 0.4, 0.2), Material("b", (0.3, 0.7, 0.3, 1), 0.6, 0.0)]
+    sc = Scene()
+    def add(name, o, mat):
+        o.setMaterial(mat); sc.addToScene(name, o)
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    add("slab", Sphere((0.0, -2.0, 0.0), (0, 0, 0, 1), (1e3, 1.0, 1e3)), m[0])               # a 1000-unit pancake
+    add("needle", Sphere((0.5, 0.0, 0.0), q, (1e-3, 4.0, 1e-3)), m[1])                         # a 4-unit needle 1 mm thick
+    c = Cube(); c.setPosition((-1.0, 0.0, 0.5)); c.setRotation(q); c.setScale((1e-3, 2.0, 1e3))   # a 1000 x 2 sheet 1 mm thick
+    add("sheet", c, m[0])
+    c = Cube(); c.setPosition((1.5, -0.5, 0.0)); c.setScale((1e-2, 1e-2, 1e-2)); add("grain", c, m[1])
+    c = Cube(); c.setPosition((1.5, -0.5 + 0.005 + 0.5, 0.0)); add("on-grain", c, m[0])          # touches the grain's top face
+    add("big", Sphere((0.0, 0.0, -600.0), (0, 0, 0, 1), (1e3, 1e3, 1e3)), m[1])
+    add("in-big", Sphere((0.0, 0.0, -100.0), q, (3.0, 1e-2, 3.0)), m[0])                        # touches nothing, sits in front of `big`
+    cams = [_cam((0.4, 0.6, 6.0), (-0.05, 0.03, 0.0, 0.998)), _cam((1.5, -0.2, 0.8), (-0.2, 0.0, 0.0, 0.98), fov=30.0),
+            _cam((40.0, 25.0, 60.0), (-0.17, 0.28, 0.05, 0.94))]
+    ref = _check_frames_and_rays(ctx, sc, cams, rng, 6.0, (0, 0, 0))
+    assert (ref[:, 0] != 0xFFFFFFFF).mean() > 0.3 and len(np.unique(ref[:, 0])) >= 7
+
+
+def test_scene_far_from_the_origin(ctx):
+    """The touching / duplicate-object scene and a random textured one 1e4 units from the origin on every axis:
+    one float ulp is 1e-3 there, the inverse model matrices cancel against 1e4, and shared faces still have
+    to resolve to the reference's object order."""
+    rng = np.random.default_rng(22)
+    off = np.array([1.0e4, -1.0e4, 1.0e4], np.float32)
+    sc = touching_scene()
+    extra, _ = pbr_scene(seed=4, n_obj=10, tex=32)
+    for k, (name, o) in enumerate(extra.getObjects().items()):
+        sc.addToScene("x" + name, o)
+    for name, o in sc.getObjects().items():
+        o.setPosition(np.asarray(o.Position, np.float32) + off)
+    cams = [_cam(tuple(off + np.array([1.2, 2.0, 6.0], np.float32)), (-0.12, 0.08, 0.0, 0.99)),
+            _cam(tuple(off + np.array([0.3, 1.0, 9.0], np.float32)), (-0.05, 0.0, 0.0, 0.999), fov=50.0)]
+    ref = _check_frames_and_rays(ctx, sc, cams, rng, 4.0, off)
+    assert (ref[:, 0] != 0xFFFFFFFF).mean() > 0.2
+
+
+def test_camera_inside_a_huge_box(ctx):
+    """The camera inside a 2e4-unit cube (scale 2e4 on the unit cube: every ray ends on it) with ordinary and
+    tiny objects around it, some touching the cube's floor."""
+    rng = np.random.default_rng(23)
+    m = [Material("wall", (0.6, 0.6, 0.7, 1), 0.8, 0.0), Material("o", (0.8, 0.4, 0.2, 1), 0.3, 0.5)]
+    sc = Scene()
+    box = Cube(); box.setScale((2e4, 2e4, 2e4)); box.setMaterial(m[0]); sc.addToScene("room", box)
+    c = Cube(); c.setPosition((0.0, -1e4 + 0.5, -4.0)); c.setMaterial(m[1]); sc.addToScene("on-floor", c)      # rests on the room's floor
+    s = Sphere((1.5, -1e4 + 1.0, -5.0), (0, 0, 0, 1), (2.0, 2.0, 2.0)); s.setMaterial(m[1]); sc.addToScene("ball", s)
+    t = Cube(); t.setPosition((-1.0, -1e4 + 1.5, -3.0)); t.setScale((1e-2, 1.0, 1e-2)); t.setMaterial(m[0]); sc.addToScene("post", t)
+    cams = [_cam((0.0, -1e4 + 1.6, 2.0), (-0.05, 0.0, 0.0, 0.999)), _cam((3.0, -1e4 + 4.0, 1.0), (-0.25, 0.2, 0.05, 0.945))]
+    ref = _check_frames_and_rays(ctx, sc, cams, rng, 5.0, (0.0, -1e4 + 2.0, -3.0))
+    assert (ref[:, 0] != 0xFFFFFFFF).mean() > 0.9
 
 
 def test_edge_cases(ctx):
@@ -393,6 +493,115 @@ def test_larger_configs_against_oracle(ctx, name, args, rect):
         assert np.array_equal(ids[y0:y1, x0:x1], rid[y0:y1, x0:x1])
         assert np.array_equal(img[y0:y1, x0:x1], ref[y0:y1, x0:x1], equal_nan=True)
         assert (rid[y0:y1, x0:x1, 0] != 0xFFFFFFFF).any()
+
+
+@pytest.mark.parametrize("name,crop", [("c3", (856, 888, 904, 936)), ("c4", (2168, 1592, 2216, 1640))])
+def test_reference_geometry_at_full_size(ctx, name, crop):
+    """BASELINE.json configs[2] and [3] at full size on the reference's own geometry (tests/golden/ref_assets.npz:
+    murasama.fbx and model.dae flattened by tests/golden/make_assets.py): C3 3840x2160 x 64 spp, C4 3840x2160 x 4 spp
+    over 1 000 944 triangles.  Too large for the CPU oracle, so: the oracle on a 48x48 crop over the model, bit for
+    bit; the interleaved bands of three ranks compose the frame; brute force equals the BVH on a strip (C3)."""
+    assert scenes.reference_assets() is not None and "reference geometry" in scenes.workload_label(name)
+    scene, cam, st = getattr(scenes, "config" + name[1:])()
+    assert (cam.width, cam.height, st.sampleCount) == ((3840, 2160, 64) if name == "c3" else (3840, 2160, 4))
+    flat = scene.flatten()
+    W, H = cam.width, cam.height
+    ctx.set_option(capi.OPT_TRAVERSAL, 0)
+    ctx.upload_scene(flat)
+    assert ctx.stats().triangles == (8972 + 12 if name == "c3" else 331 * 3024 + 12)
+    ctx.set_camera_rays(cam.preTransformRays)
+    fb = ctx.framebuffer(W, H, ids=True)
+    ctx.render(cam, st, fb)
+    a, ia, rays = ctx.read(fb, W, H), ctx.read_ids(fb, W, H), ctx.stats().rays
+    x0, y0, x1, y1 = crop
+    ref, rid, _ = orc.render(flat, cam, st, rect=crop)
+    assert np.array_equal(rid[y0:y1, x0:x1], ia[y0:y1, x0:x1])
+    assert np.array_equal(ref[y0:y1, x0:x1], a[y0:y1, x0:x1], equal_nan=True)
+    model = rid[y0:y1, x0:x1, 0]
+    assert ((model == 0) if name == "c3" else (model < 331)).mean() > 0.25, "the crop should look at the model"
+    fb2 = ctx.framebuffer(W, H, ids=True)
+    total = 0
+    for r in range(3):
+        ctx.render(cam, st, fb2, bands=(16, r, 3))
+        total += ctx.stats().rays
+    assert total == rays and np.array_equal(ctx.read(fb2, W, H), a) and np.array_equal(ctx.read_ids(fb2, W, H), ia)
+    if name == "c3":
+        ctx.set_option(capi.OPT_TRAVERSAL, 1)
+        ctx.upload_scene(flat)
+        sx0, sy0, sx1, sy1 = strip = (600, 900, 1100, 908)
+        ctx.render(cam, st, fb2, strip)
+        b, ib = ctx.read(fb2, W, H), ctx.read_ids(fb2, W, H)
+        assert np.array_equal(b[sy0:sy1, sx0:sx1], a[sy0:sy1, sx0:sx1]) and np.array_equal(ib[sy0:sy1, sx0:sx1], ia[sy0:sy1, sx0:sx1])
+        assert (ib[sy0:sy1, sx0:sx1, 0] == 0).any()
+        ctx.set_option(capi.OPT_TRAVERSAL, 0)
+    ctx.framebuffer_destroy(fb); ctx.framebuffer_destroy(fb2)
+    ctx.upload_scene(Scene().flatten())
+
+
+def test_config5_progressive_accumulation_at_full_size(ctx):
+    """BASELINE.json configs[4] as stated: the full stress scene (9 999 392-triangle terrain + 10 000 spheres =
+    13.5 M triangles, 10 001 objects) at 7680x4320, accumulated over 8 progressive frames of 1 spp
+    (progressiveFrameCount 0..7, GPURaytracer.cu:129-134).  Checked: the oracle's running mean on a crop of the
+    ACCUMULATED buffer, bit for bit; determinism of the whole sequence; interleaved bands compose a frame; and the
+    multi-GPU split (multigpu.frame_indices: each rank sums its own clamped frames, sums added, divided once)
+    against the running mean within 1e-6."""
+    import torch
+    from raytracer_amd import multigpu
+    scene, cam, st = scenes.config5()
+    W, H = cam.width, cam.height
+    assert (W, H, st.sampleCount) == (7680, 4320, 1)
+    flat = scene.flatten()
+    ctx.set_option(capi.OPT_TRAVERSAL, 0)
+    ctx.upload_scene(flat)
+    assert ctx.stats().triangles == 9999392 + 10000 * 352 and len(flat.objects) == 10001
+    ctx.set_camera_rays(cam.preTransformRays)
+    dev = torch.device("cuda", 0)
+    run = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)     # running mean, as the reference keeps it
+    one = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)     # single frames
+    fb_run, fb_one = ctx.framebuffer_wrap(run.data_ptr(), W, H), ctx.framebuffer_wrap(one.data_ptr(), W, H)
+    frames, world = 8, 2
+    sums = [torch.zeros((H, W, 4), dtype=torch.float32, device=dev) for _ in range(world)]
+    owner = {f: r for r in range(world) for f in multigpu.frame_indices(0, frames, r, world)}
+    rays = []
+    for k in range(frames):
+        st.frameCount, st.progressiveFrameCount = k, k
+        ctx.render(cam, st, fb_run)
+        rays.append(ctx.stats().rays)
+        st.progressiveFrameCount = 0
+        ctx.render(cam, st, fb_one)
+        ctx.sync()
+        sums[owner[k]] += one
+    torch.cuda.synchronize()
+    split_mean = (sums[0] + sums[1]) / frames
+    assert float((split_mean[..., :3] - run[..., :3]).abs().max()) < 1e-6
+    first = run.clone()
+    # the oracle on a crop of the accumulated buffer (brute force over 13.5 M triangles: a small crop)
+    x0, y0, x1, y1 = crop = (5070, 211, 5078, 219)   # straddles the silhouette of sphere 2884 against the terrain
+    acc = None
+    for k in range(frames):
+        st.frameCount, st.progressiveFrameCount = k, k
+        acc, rid, _ = orc.render(flat, cam, st, rect=crop, prev=acc)
+    got = run[y0:y1, x0:x1].cpu().numpy()
+    assert np.array_equal(got, acc[y0:y1, x0:x1]) and (rid[y0:y1, x0:x1, 0] != 0xFFFFFFFF).any()
+    # determinism: the whole sequence again
+    for k in range(frames):
+        st.frameCount, st.progressiveFrameCount = k, k
+        ctx.render(cam, st, fb_run)
+        assert ctx.stats().rays == rays[k]
+    ctx.sync()
+    assert torch.equal(run, first)
+    # one frame as the interleaved bands of three ranks
+    st.frameCount, st.progressiveFrameCount = 7, 0
+    ctx.render(cam, st, fb_one)
+    ctx.sync()
+    whole = one.clone()
+    one.zero_()
+    for r in range(3):
+        ctx.render(cam, st, fb_one, bands=(multigpu.BAND_ROWS, r, 3))
+    ctx.sync()
+    assert torch.equal(one, whole)
+    ctx.framebuffer_destroy(fb_run); ctx.framebuffer_destroy(fb_one)
+    ctx.upload_scene(Scene().flatten())
 
 
 def test_custom_model_from_asset_files(ctx, tmp_path):
