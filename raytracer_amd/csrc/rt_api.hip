@@ -66,7 +66,6 @@ struct rt_ctx {
     rt::ObjCull* dObjects = nullptr; uint32_t nObjects = 0;
     rt::DevMaterial* dMaterials = nullptr; size_t capMaterials = 0;
     std::vector<rt::DevMaterial> hMaterials;   // host copy of dMaterials: which textures the committed scene can reach
-    rt::DevTexture* dTextures = nullptr; size_t capTextures = 0;
 
     float4* dRays = nullptr; int32_t raysW = 0, raysH = 0;
     unsigned long long* dCounters = nullptr;   // 8 x u64
@@ -120,10 +119,15 @@ template <class T> rt_id alloc_slot(std::vector<T>& v)
 }
 template <class T> bool valid(const std::vector<T>& v, rt_id id) { return id >= 0 && (size_t)id < v.size() && v[id].live; }
 
-rt::DevMaterial to_dev(const rt_material_desc& d)
+rt::DevMaterial to_dev(const rt_material_desc& d, const std::vector<TexRec>& textures)
 {
     rt::DevMaterial m;
     memset(&m, 0, sizeof(m));
+    const rt_id t[4] = { d.texNormal, d.texAlbedo, d.texRoughness, d.texMetal };
+    for (int i = 0; i < 4; i++)
+        if (t[i] >= 0 && (size_t)t[i] < textures.size() && textures[t[i]].live) {
+            m.tex[i].data = textures[t[i]].data; m.tex[i].w = textures[t[i]].w; m.tex[i].h = textures[t[i]].h;
+        }
     memcpy(m.albedo, d.albedo, sizeof(m.albedo));
     m.roughness = d.roughness; m.metal = d.metal;
     memcpy(m.emission, d.emissionColor, sizeof(m.emission));
@@ -168,24 +172,8 @@ float band_rel_of(const float* model16, const float* inv16, int n)
     return (float)std::max(2e-4, rel);
 }
 
-// device table of the live textures (index = handle); the stream must be idle
-int upload_texture_table(rt_ctx* c)
-{
-    std::vector<rt::DevTexture> texs(c->textures.size() ? c->textures.size() : 1);
-    memset(texs.data(), 0, sizeof(rt::DevTexture) * texs.size());
-    for (size_t i = 0; i < c->textures.size(); i++)
-        if (c->textures[i].live) { texs[i].data = c->textures[i].data; texs[i].w = c->textures[i].w; texs[i].h = c->textures[i].h; }
-    if (texs.size() > c->capTextures) {
-        hipFree(c->dTextures); c->dTextures = nullptr; c->capTextures = 0;
-        RT_CHECK(c, hipMalloc((void**)&c->dTextures, sizeof(rt::DevTexture) * texs.size()));
-        c->capTextures = texs.size();
-    }
-    RT_CHECK(c, hipMemcpy(c->dTextures, texs.data(), sizeof(rt::DevTexture) * texs.size(), hipMemcpyHostToDevice));
-    return RT_OK;
-}
-
 // Lays one lane's wavefront workspace out in [base, base + return value): ~185 bytes per sample in flight
-// (path state of both ping-pong halves 128, hit 20, result 17, queue 8, exact list 4, pixel flag + redo list 8).
+// (path state of both ping-pong halves 128, hit 24, result 17, queue 8, pixel flag + redo list 8).
 // base == nullptr: sizing only.  Every array starts on a 256-byte boundary.
 size_t wf_carve(uint8_t* base, size_t slots, int levels, rt::WfBufs& w)
 {
@@ -204,13 +192,12 @@ size_t wf_carve(uint8_t* base, size_t slots, int levels, rt::WfBufs& w)
     w.accO = (float4*)take(16 * queueWords);
     w.accB = (float4*)take(16 * queueWords);
     w.hitA = (float4*)take(16 * (queueWords / 2));
-    w.hitG = (uint32_t*)take(4 * (queueWords / 2));
+    w.hitM = (uint2*)take(8 * (queueWords / 2));
     w.out = (float4*)take(16 * slots);
     w.outRays = (uint8_t*)take(slots);
     w.pixFlag = (uint32_t*)take(4 * ((slots + 63) & ~(size_t)63));
     w.redoList = (uint32_t*)take(4 * ((slots + 63) & ~(size_t)63));
     w.queue = (uint32_t*)take(4 * queueWords);
-    w.exactList = (uint32_t*)take(4 * (queueWords / 2));
     w.ctrl = (uint32_t*)take(4 * rt::wf_ctrl_words(levels));
     return off;
 }
@@ -245,7 +232,7 @@ rt::SceneView scene_view(const rt_ctx* c)
 {
     rt::SceneView s;
     s.triRef = c->built.triRef; s.triLeaf = c->built.triLeaf; s.triShade = c->built.triShade;
-    s.objects = c->dObjects; s.materials = c->dMaterials; s.textures = c->dTextures; s.nodes = c->built.nodes;
+    s.objects = c->dObjects; s.materials = c->dMaterials; s.nodes = c->built.nodes;
     s.nTris = c->built.nTris; s.nObjects = c->nObjects;
     s.rootIsValid = c->built.nTris > 0 ? 1 : 0;
     s.sceneMaxAbs = c->built.sceneMaxAbs;
@@ -363,7 +350,7 @@ int rt_ctx_destroy(rt_ctx* c)
     for (auto& t : c->textures) if (t.live) hipFree(t.data);
     for (auto& f : c->fbs) if (f.live) { if (f.owned) hipFree(f.data); hipFree(f.ids); }
     rt::free_scene(c->built);
-    hipFree(c->dObjects); hipFree(c->dMaterials); hipFree(c->dTextures); hipFree(c->dRays); hipFree(c->dCounters); hipFree(c->dWork); hipFree(c->dRedoList);
+    hipFree(c->dObjects); hipFree(c->dMaterials); hipFree(c->dRays); hipFree(c->dCounters); hipFree(c->dWork); hipFree(c->dRedoList);
     free_wf(c);
     if (c->hCounters) hipHostFree(c->hCounters);
     if (c->evBegin) hipEventDestroy(c->evBegin);
@@ -511,10 +498,6 @@ int rt_texture_destroy(rt_ctx* c, rt_id id)
     if (c->committed) {
         for (const rt::DevMaterial& m : c->hMaterials)
             if (m.texNormal == id || m.texAlbedo == id || m.texRoughness == id || m.texMetal == id) c->committed = false;
-        if (c->committed && (size_t)id < c->capTextures) {
-            const rt::DevTexture none = { nullptr, 0, 0 };
-            RT_CHECK(c, hipMemcpy(c->dTextures + id, &none, sizeof(none), hipMemcpyHostToDevice));
-        }
     }
     hipFree(c->textures[id].data);
     c->textures[id] = TexRec();
@@ -543,11 +526,9 @@ int rt_material_update(rt_ctx* c, rt_id id, const rt_material_desc* d)
     c->materials[id].desc = *d;
     // hot update of a committed scene (the reference re-sends the GPUMaterial, Material.hpp:155-159)
     if (c->committed && (size_t)id < c->capMaterials) {
-        const rt::DevMaterial m = to_dev(*d);
+        // the record carries the descriptors of its maps, so a texture created after the commit binds like any other
+        const rt::DevMaterial m = to_dev(*d, c->textures);
         RT_CHECK(c, hipStreamSynchronize(c->stream));
-        // textures created (or re-created in a freed slot) after the commit: bring the device table up to date first
-        r = upload_texture_table(c);
-        if (r) return r;
         RT_CHECK(c, hipMemcpy(c->dMaterials + id, &m, sizeof(m), hipMemcpyHostToDevice));
         c->hMaterials[id] = m;
     }
@@ -636,7 +617,6 @@ int rt_scene_commit(rt_ctx* c, const rt_id* objects, const float* model16, const
     c->committed = false;
     hipFree(c->dObjects); c->dObjects = nullptr; c->nObjects = 0;
     hipFree(c->dMaterials); c->dMaterials = nullptr; c->capMaterials = 0;
-    hipFree(c->dTextures); c->dTextures = nullptr; c->capTextures = 0;
 
     if (n > 0) {
         RT_CHECK(c, hipMalloc((void**)&c->dObjects, sizeof(rt::ObjCull) * (size_t)n));
@@ -647,15 +627,13 @@ int rt_scene_commit(rt_ctx* c, const rt_id* objects, const float* model16, const
         std::vector<rt::DevMaterial> mats(c->materials.size() ? c->materials.size() : 1);
         memset(mats.data(), 0, sizeof(rt::DevMaterial) * mats.size());
         for (size_t i = 0; i < c->materials.size(); i++)
-            if (c->materials[i].live) mats[i] = to_dev(c->materials[i].desc);
+            if (c->materials[i].live) mats[i] = to_dev(c->materials[i].desc, c->textures);
             else mats[i].texNormal = mats[i].texAlbedo = mats[i].texRoughness = mats[i].texMetal = -1; // unused slot: binds nothing
         if (c->materials.empty()) mats[0].texNormal = mats[0].texAlbedo = mats[0].texRoughness = mats[0].texMetal = -1;
         RT_CHECK(c, hipMalloc((void**)&c->dMaterials, sizeof(rt::DevMaterial) * mats.size()));
         RT_CHECK(c, hipMemcpy(c->dMaterials, mats.data(), sizeof(rt::DevMaterial) * mats.size(), hipMemcpyHostToDevice));
         c->capMaterials = mats.size();
         c->hMaterials = mats;
-        const int tr = upload_texture_table(c);
-        if (tr) return tr;
     }
 
     rt::Segment* dSegs = nullptr;

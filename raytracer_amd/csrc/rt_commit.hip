@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void flatten_kernel(const Segment* __restrict_
         TriIsect ti;
         ti.v0x = v[0][0]; ti.v0y = v[0][1]; ti.v0z = v[0][2]; ti.gid = g;
         ti.v1x = v[1][0]; ti.v1y = v[1][1]; ti.v1z = v[1][2]; ti.obj = sg.obj;
-        ti.v2x = v[2][0]; ti.v2y = v[2][1]; ti.v2z = v[2][2]; ti.pad = 0;
+        ti.v2x = v[2][0]; ti.v2y = v[2][1]; ti.v2z = v[2][2]; ti.mat = sg.materialId | (sg.nrm ? 0x80000000u : 0u);
         triRef[g] = ti;
 
         TriShade ts;

@@ -31,7 +31,7 @@ constexpr int kCounterStride = 16; // u64 per slot
 struct TriIsect {
     float v0x, v0y, v0z; uint32_t gid;   // rank in reference iteration order = tie-break key
     float v1x, v1y, v1z; uint32_t obj;   // object index (array order of rt_scene_commit)
-    float v2x, v2y, v2z; uint32_t pad;
+    float v2x, v2y, v2z; uint32_t mat;   // TriShade::matFlags: the trace kernels hand the winner's material to the shade kernel
 };
 static_assert(sizeof(TriIsect) == 48, "TriIsect layout");
 
@@ -60,15 +60,19 @@ struct DevTexture {
     int32_t w, h;
 };
 
-struct DevMaterial { // 64 B
+// 128 B: the material constants and, inline, the descriptors of its four maps -- the shading chain is then
+// hit -> material -> texels instead of hit -> material -> descriptor table -> texels (each step a dependent
+// fetch at ~800 cycles of L2 latency; measured, that chain, not bandwidth, was what wf_shade waited for)
+struct DevMaterial {
     float albedo[4];
     float roughness, metal;
     float emission[3];
     float strength;
-    int32_t texNormal, texAlbedo, texRoughness, texMetal;
+    int32_t texNormal, texAlbedo, texRoughness, texMetal;  // texture handle or -1 (the maps below are bound iff >= 0)
     uint32_t pad[2];
+    DevTexture tex[4];                                       // normal, albedo, roughness, metal
 };
-static_assert(sizeof(DevMaterial) == 64, "DevMaterial layout");
+static_assert(sizeof(DevMaterial) == 128, "DevMaterial layout");
 
 // 64 B four-wide BVH node with quantised child boxes (after Ylitie, Karras & Laine 2017,
 // "Efficient incoherent ray traversal on GPUs through compressed wide BVHs").  Measured on MI355X
@@ -97,7 +101,6 @@ struct SceneView {
     const TriShade* triShade;  // [nTris] reference order
     const ObjCull* objects;    // [nObjects]
     const DevMaterial* materials;
-    const DevTexture* textures;
     const BvhNode* nodes;
     uint32_t nTris;
     uint32_t nObjects;
@@ -124,14 +127,14 @@ struct WfBufs {
     float4* accO;        // [2][kWfStripes][subCap] outgoing light, checksum bits
     float4* accB;        // [2][kWfStripes][subCap] beta accumulation
     float4* hitA;        // [kWfStripes][subCap] t, b0, b1, b2 of the closest hit (trace -> shade of one level)
-    uint32_t* hitG;      // [kWfStripes][subCap] gid | flags
+    uint2* hitM;         // [kWfStripes][subCap] gid | flags, object: with the object named here the shade kernel starts the triangle
+                         // and the object-cull fetches of a hit at once instead of one after the other
     float4* out;         // [slot] finished sample: exposure-corrected rgb, checksum bits
     uint8_t* outRays;    // [slot] closest-hit queries of the finished sample
     uint32_t* pixFlag;   // [pixelInChunk] != 0: flagged for the redo launch
     uint32_t* redoList;  // [pixelInChunk] the chunk's flagged pixels (a lane's chunks run one after the other, so they share it)
     uint32_t* queue;     // [2][kWfStripes][subCap] slots, ping-pong over levels
-    uint32_t* exactList; // [kWfStripes][subCap] hit positions of the rays of the current level that need the exact emulation, listed per stripe
-    uint32_t* ctrl;      // [level][2][kWfStripes][kWfCtrlStride]: counts, cursors; then the redo count; then per level one exact count per stripe (one same-address atomic stream per stripe: a single counter capped the trace kernels at its ~90 appends per microsecond)
+    uint32_t* ctrl;      // [level][2][kWfStripes][kWfCtrlStride]: counts, cursors; then the redo count
     uint32_t subCap;
     uint32_t nSlots;
     uint32_t nPix;       // pixels of the chunk = tiles * 64 (edge tiles include pixels outside the rectangle)
@@ -142,14 +145,9 @@ struct WfBufs {
 // words of WfBufs::ctrl for `levels` bounce levels, and where the two kinds of single counters sit in it
 __host__ __device__ inline size_t wf_ctrl_words(int levels)
 {
-    return (size_t)(levels + 1) * 2 * kWfStripes * kWfCtrlStride + (size_t)(1 + levels * kWfStripes) * kWfCtrlStride;
+    return (size_t)(levels + 1) * 2 * kWfStripes * kWfCtrlStride + (size_t)kWfCtrlStride;
 }
 __host__ __device__ inline size_t wf_ctrl_redo(int levels) { return (size_t)(levels + 1) * 2 * kWfStripes * kWfCtrlStride; }
-__host__ __device__ inline size_t wf_ctrl_exact(int levels, int level, int stripe)
-{
-    return wf_ctrl_redo(levels) + (size_t)(1 + level * kWfStripes + stripe) * kWfCtrlStride;
-}
-
 struct RenderArgs {
     SceneView scene;
     // CameraParams (GPURaytracer.hpp:60-69)

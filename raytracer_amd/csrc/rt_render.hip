@@ -162,8 +162,10 @@ struct Surface {
 };
 
 // winner attributes (:435-548) + material evaluation (:363-377, Material.cu:268-323)
+// matHint: the winner's TriShade::matFlags when the caller already has it (the wavefront hit record), so that the
+// material fetch does not wait for the triangle record; kNoHit = take it from the record
 __device__ __forceinline__ Surface shade_surface(const SceneView& s, const Hit& h, uint32_t& objOut, uint32_t& meshOut,
-                                                 uint32_t& triOut)
+                                                 uint32_t& triOut, uint32_t matHint = kNoHit)
 {
     const float4* tp = reinterpret_cast<const float4*>(s.triRef + h.gid);
     const float4 A = tp[0], B = tp[1], C = tp[2];
@@ -171,10 +173,20 @@ __device__ __forceinline__ Surface shade_surface(const SceneView& s, const Hit& 
     const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
     // TriShade: n0 = s0.xyz, n1 = (s0.w, s1.x, s1.y), n2 = (s1.z, s1.w, s2.x),
     //           uv0 = (s2.y, s2.z), uv1 = (s2.w, s3.x), uv2 = (s3.y, s3.z), obj = s3.w, mesh,tri,matFlags = s4.xyz
-    const uint32_t matFlags = __float_as_uint(s4.z);
+    const uint32_t matFlags = matHint != kNoHit ? matHint : __float_as_uint(s4.z);
     objOut = __float_as_uint(s3.w); meshOut = __float_as_uint(s4.x); triOut = __float_as_uint(s4.y);
     const bool hasNormals = (matFlags >> 31) != 0;
-    const DevMaterial m = s.materials[matFlags & 0x7FFFFFFFu];
+    // constants now, each map's descriptor where it is sampled: the whole 128-byte record held 32 registers to the end
+    const DevMaterial* __restrict__ mp = s.materials + (matFlags & 0x7FFFFFFFu);
+    struct { float albedo[4]; float roughness, metal; float emission[3]; float strength; int32_t texNormal, texAlbedo, texRoughness, texMetal; } m;
+    {
+        const float4* q4 = reinterpret_cast<const float4*>(mp);
+        const float4 c0 = q4[0], c1 = q4[1], c2 = q4[2];
+        const int2 c3 = *reinterpret_cast<const int2*>(q4 + 3);
+        m.albedo[0] = c0.x; m.albedo[1] = c0.y; m.albedo[2] = c0.z; m.albedo[3] = c0.w;
+        m.roughness = c1.x; m.metal = c1.y; m.emission[0] = c1.z; m.emission[1] = c1.w; m.emission[2] = c2.x; m.strength = c2.y;
+        m.texNormal = __float_as_int(c2.z); m.texAlbedo = __float_as_int(c2.w); m.texRoughness = c3.x; m.texMetal = c3.y;
+    }
 
     const V4 e1 = mk4(B.x - A.x, B.y - A.y, B.z - A.z, 0.0f);
     const V4 e2 = mk4(C.x - A.x, C.y - A.y, C.z - A.z, 0.0f);
@@ -202,11 +214,11 @@ __device__ __forceinline__ Surface shade_surface(const SceneView& s, const Hit& 
     const float u = u0 * h.b0 + u1 * h.b1 + u2 * h.b2;
     const float v = w0 * h.b0 + w1 * h.b1 + w2 * h.b2;
 
-    o.albedo = m.texAlbedo < 0 ? mk4(m.albedo[0], m.albedo[1], m.albedo[2], m.albedo[3]) : tex2d_norm(s.textures[m.texAlbedo], u, v);
+    o.albedo = m.texAlbedo < 0 ? mk4(m.albedo[0], m.albedo[1], m.albedo[2], m.albedo[3]) : tex2d_norm(mp->tex[1], u, v);
     V4 nl;
     if (m.texNormal < 0) nl = mk4(0.0f, 0.0f, 1.0f, 0.0f);
     else {
-        const V4 n = tex2d_norm(s.textures[m.texNormal], u, v);
+        const V4 n = tex2d_norm(mp->tex[0], u, v);
         nl = mk4(n.x * 2 - 1.0f, n.y * 2 - 1.0f, n.z * 2 - 1.0f, 0.0f);
     }
     // matVecMul(tbn, nl) with tbn columns (T, B, N, (0,0,0,1)), :522-526, :728-743
@@ -215,8 +227,8 @@ __device__ __forceinline__ Surface shade_surface(const SceneView& s, const Hit& 
                       tangent.z * nl.x + bitangent.z * nl.y + normal.z * nl.z + 0.0f * nl.w,
                       0.0f * nl.x + 0.0f * nl.y + 0.0f * nl.z + 1.0f * nl.w);
     o.normal = normalize4(nw);
-    o.roughness = m.texRoughness < 0 ? m.roughness : tex2d_norm(s.textures[m.texRoughness], u, v).x;
-    o.metal = m.texMetal < 0 ? m.metal : tex2d_norm(s.textures[m.texMetal], u, v).x;
+    o.roughness = m.texRoughness < 0 ? m.roughness : tex2d_norm(mp->tex[2], u, v).x;
+    o.metal = m.texMetal < 0 ? m.metal : tex2d_norm(mp->tex[3], u, v).x;
     o.emission = mk4(m.emission[0], m.emission[1], m.emission[2], m.strength);
     return o;
 }
@@ -260,7 +272,8 @@ struct PathAcc {
 // failure is reported through cullFail (the pixel then goes to the redo launch).
 __device__ __forceinline__ bool shade_segment(const RenderArgs& a, const Hit& h, Ray& ray, uint32_t& seed, uint32_t sample,
                                               int i, PathAcc& p, LaneStats& st, uint32_t& checksum, uint32_t* primary,
-                                              uint32_t cullObj = kNoHit, float cullMax = 0.0f, bool* cullFail = nullptr)
+                                              uint32_t cullObj = kNoHit, float cullMax = 0.0f, bool* cullFail = nullptr,
+                                              uint32_t matHint = kNoHit)
 {
     if (h.gid == kNoHit) {
         checksum += seg_hash(kNoHit, kNoHit, kNoHit, sample, (uint32_t)i);
@@ -281,7 +294,7 @@ __device__ __forceinline__ bool shade_segment(const RenderArgs& a, const Hit& h,
         if (!object_cull_pass(tmin, bfar, cullMax)) *cullFail = true;
     }
 #endif
-    const Surface sf = shade_surface(a.scene, h, ho, hm, ht);
+    const Surface sf = shade_surface(a.scene, h, ho, hm, ht, matHint);
     checksum += seg_hash(ho, hm, ht, sample, (uint32_t)i);
     if (i == 0 && sample == 0) { primary[0] = ho; primary[1] = hm; primary[2] = ht; }
 
@@ -911,19 +924,16 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
 #endif
         // ---- results of the lanes that finished
         if (have && !trav_running(T)) {
-            // a hit of another object inside the tie band: the ray is listed for wf_exact, which replaces this
-            // record before the level is shaded; a dropped stack entry flags the pixel for the redo launch
+            // a hit of another object inside the tie band, or a dropped stack entry: the pixel is flagged for the redo
+            // launch, which traces it with the exact in-order emulation inline (6e-6 of the rays on C2 / C4, 4e-4 on C5;
+            // a pass per level over a list of such rays cost four near-empty launches per frame, 0.12 ms of C2's 6.8)
             bool band = false;
             const Hit h = trav_result(T, ray, band);
             const bool over = stack.dropped;
             stack.dropped = false;
-            if (band) { // listed under the stripe the ray sits in: that list cannot overflow
-                st.slow++;
-                const uint32_t bs = hitPos / w.subCap;
-                w.exactList[(size_t)bs * w.subCap + atomicAdd(w.ctrl + wf_ctrl_exact(levels, level, (int)bs), 1u)] = hitPos;
-            }
+            if (band) st.slow++;
             w.hitA[hitPos] = make_float4(h.t, h.b0, h.b1, h.b2);
-            w.hitG[hitPos] = (h.gid == kNoHit ? kWfMiss : h.gid) | (over ? kWfDanger : 0u);
+            w.hitM[hitPos] = make_uint2((h.gid == kNoHit ? kWfMiss : h.gid) | (over || band ? kWfDanger : 0u), T.bestObj);
             have = false;
         }
 #ifdef RT_PHASE_TIMERS
@@ -988,9 +998,6 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
 // gives: a node is entered when any lane's ray enters it, and a lane that does not merely tests
 // triangles its ray cannot hit.  Only worth it for coherent rays: after the first bounce the union of
 // 64 rays' nodes is most of the tree.
-#ifndef RT_EXACT_GRID
-#define RT_EXACT_GRID 128u
-#endif
 #ifndef RT_PK_OCC
 #define RT_PK_OCC 6
 #endif
@@ -1127,12 +1134,9 @@ __global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const R
             bool band = false;
             const Hit hres = trav_result(T, ray, band);
             const uint32_t hitPos = (uint32_t)wf_hit_pos(w, blockStripe, off + (uint32_t)lane);
-            if (band) {
-                st.slow++;
-                w.exactList[(size_t)blockStripe * w.subCap + atomicAdd(w.ctrl + wf_ctrl_exact(levels, level, (int)blockStripe), 1u)] = hitPos;
-            }
+            if (band) st.slow++;
             w.hitA[hitPos] = make_float4(hres.t, hres.b0, hres.b1, hres.b2);
-            w.hitG[hitPos] = (hres.gid == kNoHit ? kWfMiss : hres.gid) | (overflow ? kWfDanger : 0u);
+            w.hitM[hitPos] = make_uint2((hres.gid == kNoHit ? kWfMiss : hres.gid) | (overflow || band ? kWfDanger : 0u), T.bestObj);
         }
 #ifdef RT_PHASE_TIMERS
         if (lane == 0) { // slots as in wf_trace: burst = the walk, write = results, refill = claim + ray fetch + set-up
@@ -1149,128 +1153,202 @@ __global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const R
     flush_stats(a, st, wgCnt);
 }
 
-// The rays of a level whose closest hit depends on the reference's object order (another object's hit
-// inside the tie band): traced again with the exact in-order emulation inline, one
-// lane per ray, between the level's trace and shade launches.  Exits at once when the list is empty.
-__global__ __launch_bounds__(256) void wf_exact_kernel(const RenderArgs a, const WfBufs w, const int level, const int levels)
-{
-    __shared__ uint32_t ldsStack[kLdsStack * kBlock];
-    __shared__ uint32_t wgCnt[8];
-    uint32_t ovf[kStackDepth - kLdsStack];
-    Stack stack; stack.lds = ldsStack + threadIdx.x; stack.ovf = ovf;
-    LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
-    // the stripes' lists read as one: entry i belongs to the last stripe whose running total is <= i
-    __shared__ uint32_t listBase[kWfStripes + 1];
-    if (threadIdx.x < 64) {
-        const uint32_t cnt = w.ctrl[wf_ctrl_exact(levels, level, (int)threadIdx.x)];
-        uint32_t incl = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
-            if ((int)threadIdx.x >= d) incl += up;
-        }
-        listBase[threadIdx.x + 1] = incl;
-        if (threadIdx.x == 0) listBase[0] = 0u;
-    }
-    __syncthreads();
-    const uint32_t n = listBase[kWfStripes];
-    const size_t half = (size_t)(level & 1) * kWfStripes * (size_t)w.subCap;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        uint32_t ls = 0;
-#pragma unroll
-        for (uint32_t step = kWfStripes / 2; step > 0; step >>= 1)
-            if (listBase[ls + step] <= i) ls += step;
-        const uint32_t hp = w.exactList[(size_t)ls * w.subCap + (i - listBase[ls])];
-        const float4 o = wf_ray_origin(a, w, level, half + hp), d = w.rayD[half + hp];
-        Ray ray; ray.ox = o.x; ray.oy = o.y; ray.oz = o.z; ray.maxDist = o.w; ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
-        Hit h;
-        if (!trace_band_table(a.scene, ray, w.hitA[hp].x, stack, st.bvh, h)) {
-            bool unused = false;
-            h = closest_hit<3>(a.scene, ray, stack, st, unused);
-        }
-        w.hitA[hp] = make_float4(h.t, h.b0, h.b1, h.b2);
-        w.hitG[hp] = (h.gid == kNoHit ? kWfMiss : h.gid) | (w.hitG[hp] & kWfDanger);
-    }
-    st.rays = 0; st.slow = 0; // queries are counted per finished sample, tie-band rays by wf_trace
-    flush_stats(a, st, wgCnt);
-}
-
-// material evaluation, BRDF and bounce ray of one level (:172-242): one lane per live path
+// material evaluation, BRDF and bounce ray of one level (:172-242): one lane per live path.
+//
+// Levels >= 1 (DEAL): a quarter of a bounce level's entries are hits and the surface code is several times the sky
+// code, so waves of entries in queue order ran it with 18 of 64 lanes.  A workgroup therefore takes a BATCH of
+// kShadeBatch x 256 consecutive entries of a stripe, classifies them in one pass and deals them out -- hits first,
+// in queue order -- into a list in LDS; its waves then work through that list 64 entries at a time, each at its own
+// pace: all but one of the 64-entry runs are all-hit or all-miss, and no barrier ties a sky wave to a surface wave's
+// chain of dependent fetches (with one barrier pair per 256 entries the sky waves spent their time waiting for the
+// surface wave of their workgroup, and dealing bought nothing).
+// The hit record names the object (WfBufs::hitM), so a hit lane's triangle and object-cull fetches go out together.
 #ifndef RT_SHADE_OCC
 #define RT_SHADE_OCC 4
 #endif
+#ifndef RT_SHADE_BATCH
+#define RT_SHADE_BATCH 16
+#endif
+constexpr uint32_t kShadeBatch = RT_SHADE_BATCH;   // pieces of 256 entries per batch
+
+// one entry of a level: reads its path state, shades, writes the finished sample or returns the survivor
+struct ShadeOut {
+    bool more;
+    uint32_t slot, seed, chk;
+    Ray ray;
+    PathAcc acc;
+};
+__device__ __forceinline__ void shade_entry(const RenderArgs& a, const WfBufs& w, const int level, const uint32_t stripe,
+                                            const uint32_t off, const bool mine, LaneStats& st, ShadeOut& o)
+{
+    const size_t pin = wf_pos(w, level, stripe, off), ph = wf_hit_pos(w, stripe, off);
+    o.more = false;
+    o.seed = o.chk = 0u;
+    o.ray.ox = o.ray.oy = o.ray.oz = o.ray.dx = o.ray.dy = o.ray.dz = o.ray.maxDist = 0.0f;
+    o.acc.ox = o.acc.oy = o.acc.oz = o.acc.bx = o.acc.by = o.acc.bz = 0.0f;
+    o.slot = mine ? w.queue[pin] : kWfHole;
+    if (o.slot == kWfHole) return;
+    const uint2 hM = w.hitM[ph];
+    const uint32_t spp = a.sampleCount;
+    const uint32_t pix = o.slot / spp, sidx = o.slot - pix * spp;
+    const float4 d = w.rayD[pin];
+    const float4 aO = level == 0 ? make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u)) : w.accO[pin];
+    const float4 aB = level == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : w.accB[pin];
+    Ray ray; ray.ox = ray.oy = ray.oz = 0.0f; ray.maxDist = 0.0f; ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
+    uint32_t seed = __float_as_uint(d.w), checksum = __float_as_uint(aO.w);
+    PathAcc acc; acc.ox = aO.x; acc.oy = aO.y; acc.oz = aO.z; acc.bx = aB.x; acc.by = aB.y; acc.bz = aB.z;
+    Hit h; h.t = 0.0f; h.b0 = h.b1 = h.b2 = 0.0f;
+    h.gid = (hM.x & kWfMiss) == kWfMiss ? kNoHit : (hM.x & kWfMiss);
+#if defined(RT_ABL_SHADE) && (RT_ABL_SHADE & 2)
+    if (level > 0) h.gid = kNoHit; // timing only: every entry takes the sky path
+#endif
+    bool danger = (hM.x & kWfDanger) != 0u;
+    uint32_t cullObj = kNoHit;
+    float m0 = 0.0f;
+    if (h.gid != kNoHit) { // the ray's origin and the hit's distance / barycentrics matter to a hit only
+        const float4 ro = wf_ray_origin(a, w, level, pin), hA = w.hitA[ph];
+        ray.ox = ro.x; ray.oy = ro.y; ray.oz = ro.z; m0 = ro.w;
+        h.t = hA.x; h.b0 = hA.y; h.b1 = hA.z; h.b2 = hA.w;
+        ray.maxDist = h.t;
+        cullObj = hM.y;
+    }
+    uint32_t primary[3] = { kNoHit, kNoHit, kNoHit };
+    o.more = shade_segment(a, h, ray, seed, sidx, level, acc, st, checksum, primary, cullObj, m0, &danger);
+#ifdef RT_DEBUG_FLAGS
+    if (danger) printf("flag: level %d pix %u overflow %d gid %u\n", level, pix, (int)((hM.x & kWfDanger) != 0u), h.gid);
+#endif
+    if (danger) w.pixFlag[pix] = 1u;
+    if (level == 0 && sidx == 0 && a.ids) {
+        int x, y;
+        wf_pixel(a, w, pix, x, y);
+        uint32_t* idp = reinterpret_cast<uint32_t*>(a.ids + ((size_t)y * (size_t)a.width + (size_t)x));
+        idp[0] = primary[0]; idp[1] = primary[1]; idp[2] = primary[2];
+    }
+    if (o.more) { // kept in registers until the survivors' positions are known
+        o.ray = ray; o.seed = seed; o.chk = checksum; o.acc = acc;
+    } else
+#if defined(RT_ABL_SHADE) && (RT_ABL_SHADE & 1)
+    if (level == 0) // timing only: no result stores past the camera rays
+#endif
+    { // exposureCorrection (:690-698), per sample
+        const size_t oi = wf_out_index(pix, sidx, spp);
+        w.out[oi] = make_float4(1.0f - rtd::exp_f(-acc.ox * a.exposure), 1.0f - rtd::exp_f(-acc.oy * a.exposure),
+                                1.0f - rtd::exp_f(-acc.oz * a.exposure), __uint_as_float(checksum));
+        w.outRays[oi] = (uint8_t)(level + 1 > 255 ? 255 : level + 1);
+    }
+#if defined(RT_ABL_SHADE) && (RT_ABL_SHADE & 4)
+    if (level > 0) o.more = false; // timing only: no survivors
+#endif
+}
+
+// survivors go to the same stripe of the next level's queue: one atomic per wave
+__device__ __forceinline__ void shade_append(const WfBufs& w, const int level, const uint32_t stripe, const ShadeOut& o)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long mm = __ballot(o.more);
+    if (mm == 0ull) return;
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(wf_count(w, level + 1, (int)stripe), (uint32_t)__popcll(mm));
+    base = __shfl(base, 0);
+    if (o.more) {
+        const size_t po = wf_pos(w, level + 1, stripe, base + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull)));
+        w.queue[po] = o.slot;
+        w.rayO[po] = make_float4(o.ray.ox, o.ray.oy, o.ray.oz, o.ray.maxDist);
+        w.rayD[po] = make_float4(o.ray.dx, o.ray.dy, o.ray.dz, __uint_as_float(o.seed));
+        w.accO[po] = make_float4(o.acc.ox, o.acc.oy, o.acc.oz, __uint_as_float(o.chk));
+        w.accB[po] = make_float4(o.acc.bx, o.acc.by, o.acc.bz, 0.0f);
+    }
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is also a release fence for global memory: it
+// waits (s_waitcnt vmcnt(0)) until every store the wave has issued -- here the survivors' path state on its way to
+// HBM -- is acknowledged.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <bool DEAL>
 __global__ __launch_bounds__(256, RT_SHADE_OCC) void wf_shade_kernel(const RenderArgs a, const WfBufs w, const int level)
 {
     __shared__ uint32_t wgCnt[8];
     LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
-    const int lane = threadIdx.x & 63;
-    const uint32_t piecesPerStripe = (w.subCap + 255u) / 256u;
-    const uint32_t total = piecesPerStripe * kWfStripes;
-    for (uint32_t piece = blockIdx.x; piece < total; piece += gridDim.x) {
-        const uint32_t stripe = piece % kWfStripes, pieceBase = (piece / kWfStripes) * 256u;
-        const uint32_t off = pieceBase + threadIdx.x;
-        const uint32_t cnt = *wf_count(w, level, (int)stripe);
-        if (pieceBase >= cnt) continue; // uniform per workgroup
-        const size_t pin = wf_pos(w, level, stripe, off), ph = wf_hit_pos(w, stripe, off);
-        // the hit word gates the longest chain of dependent fetches (triangle -> object, material -> texture -> texels):
-        // it goes out first, so that the chain starts while the rest of the path state is still arriving
-        const uint32_t hG0 = off < cnt ? w.hitG[ph] : kWfMiss;
-        const uint32_t slot = off < cnt ? w.queue[pin] : kWfHole;
-        bool more = false;
-        Ray nray; nray.ox = nray.oy = nray.oz = nray.dx = nray.dy = nray.dz = nray.maxDist = 0.0f;
-        PathAcc nacc; nacc.ox = nacc.oy = nacc.oz = nacc.bx = nacc.by = nacc.bz = 0.0f;
-        uint32_t nseed = 0, nchk = 0;
-        if (slot != kWfHole) {
-            const uint32_t spp = a.sampleCount;
-            const uint32_t pix = slot / spp, sidx = slot - pix * spp;
-            const float4 o = wf_ray_origin(a, w, level, pin), d = w.rayD[pin], hA = w.hitA[ph];
-            const float4 aO = level == 0 ? make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u)) : w.accO[pin];
-            const float4 aB = level == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : w.accB[pin];
-            const uint32_t hG = hG0;
-            Ray ray; ray.ox = o.x; ray.oy = o.y; ray.oz = o.z; ray.maxDist = o.w; ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
-            uint32_t seed = __float_as_uint(d.w), checksum = __float_as_uint(aO.w);
-            PathAcc acc; acc.ox = aO.x; acc.oy = aO.y; acc.oz = aO.z; acc.bx = aB.x; acc.by = aB.y; acc.bz = aB.z;
-            Hit h; h.t = hA.x; h.b0 = hA.y; h.b1 = hA.z; h.b2 = hA.w;
-            h.gid = (hG & kWfMiss) == kWfMiss ? kNoHit : (hG & kWfMiss);
-            bool danger = (hG & kWfDanger) != 0u;
-            uint32_t cullObj = kNoHit;
-            const float m0 = ray.maxDist;
-            if (h.gid != kNoHit) { cullObj = a.scene.triRef[h.gid].obj; ray.maxDist = h.t; }
-            uint32_t primary[3] = { kNoHit, kNoHit, kNoHit };
-            more = shade_segment(a, h, ray, seed, sidx, level, acc, st, checksum, primary, cullObj, m0, &danger);
-#ifdef RT_DEBUG_FLAGS
-            if (danger) printf("flag: level %d pix %u overflow %d gid %u\n", level, pix, (int)((hG & kWfDanger) != 0u), h.gid);
-#endif
-            if (danger) w.pixFlag[pix] = 1u;
-            if (level == 0 && sidx == 0 && a.ids) {
-                int x, y;
-                wf_pixel(a, w, pix, x, y);
-                uint32_t* idp = reinterpret_cast<uint32_t*>(a.ids + ((size_t)y * (size_t)a.width + (size_t)x));
-                idp[0] = primary[0]; idp[1] = primary[1]; idp[2] = primary[2];
-            }
-            if (more) { // kept in registers until the survivors' positions are known
-                nray = ray; nseed = seed; nchk = checksum; nacc = acc;
-            } else { // exposureCorrection (:690-698), per sample
-                const size_t oi = wf_out_index(pix, sidx, spp);
-                w.out[oi] = make_float4(1.0f - rtd::exp_f(-acc.ox * a.exposure), 1.0f - rtd::exp_f(-acc.oy * a.exposure),
-                                        1.0f - rtd::exp_f(-acc.oz * a.exposure), __uint_as_float(checksum));
-                w.outRays[oi] = (uint8_t)(level + 1 > 255 ? 255 : level + 1);
-            }
+    if (!DEAL) { // queue order, one piece of 256 entries at a time
+        const uint32_t piecesPerStripe = (w.subCap + 255u) / 256u;
+        const uint32_t total = piecesPerStripe * kWfStripes;
+        for (uint32_t piece = blockIdx.x; piece < total; piece += gridDim.x) {
+            const uint32_t stripe = piece % kWfStripes, off = (piece / kWfStripes) * 256u + threadIdx.x;
+            const uint32_t cnt = *wf_count(w, level, (int)stripe);
+            if (off - threadIdx.x >= cnt) continue; // uniform per workgroup
+            ShadeOut o; // per entry: nothing of it lives across the loop's back edge
+            shade_entry(a, w, level, stripe, off, off < cnt, st, o);
+            shade_append(w, level, stripe, o);
         }
-        // survivors go to the same stripe of the next level's queue: one atomic per wave
-        const unsigned long long mm = __ballot(more);
-        if (mm != 0ull) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(wf_count(w, level + 1, (int)stripe), (uint32_t)__popcll(mm));
-            base = __shfl(base, 0);
-            if (more) {
-                const size_t po = wf_pos(w, level + 1, stripe, base + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull)));
-                w.queue[po] = slot;
-                w.rayO[po] = make_float4(nray.ox, nray.oy, nray.oz, nray.maxDist);
-                w.rayD[po] = make_float4(nray.dx, nray.dy, nray.dz, __uint_as_float(nseed));
-                w.accO[po] = make_float4(nacc.ox, nacc.oy, nacc.oz, __uint_as_float(nchk));
-                w.accB[po] = make_float4(nacc.bx, nacc.by, nacc.bz, 0.0f);
+    } else {
+        constexpr uint32_t kBatchEntries = kShadeBatch * 256u;
+        __shared__ uint16_t perm[kBatchEntries];            // dealt list: hits [0, nHit), misses [nHit, nLive), entries of the batch
+        __shared__ uint32_t runCnt[2][kShadeBatch * 4 + 1]; // hits / misses per (piece, wave) of the classification pass, then their prefix sums
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        // pieces per batch: kShadeBatch for a full level; fewer for a thin one, so that every workgroup still gets a batch
+        // (a deep level of a small frame holds a few thousand entries per stripe)
+        const uint32_t piecesPerStripe = (w.subCap + 255u) / 256u;
+        const uint32_t total = piecesPerStripe * kWfStripes;     // as many batches as there would be of one piece each
+        const uint32_t wantPerStripe = (gridDim.x * 2u + kWfStripes - 1u) / kWfStripes;
+        for (uint32_t batch = blockIdx.x; batch < total; batch += gridDim.x) {
+            const uint32_t stripe = batch % kWfStripes;
+            const uint32_t cnt = *wf_count(w, level, (int)stripe);
+            uint32_t nbp = ((cnt + 255u) / 256u + wantPerStripe - 1u) / wantPerStripe;
+            nbp = nbp < 1u ? 1u : (nbp > kShadeBatch ? kShadeBatch : nbp);
+            const uint32_t base = (batch / kWfStripes) * nbp * 256u;
+            if (base >= cnt) continue; // uniform per workgroup
+            // ---- classification pass: every thread looks at kShadeBatch entries, 256 apart
+            uint32_t cls = 0u; // 2 bits per piece: 1 = hit, 2 = miss
+#pragma unroll
+            for (uint32_t j = 0; j < kShadeBatch; j++) {
+                const uint32_t off = base + j * 256u + threadIdx.x;
+                const bool in = j < nbp && off < cnt;
+                const uint32_t g0 = in ? w.hitM[wf_hit_pos(w, stripe, off)].x : kWfMiss;
+                const uint32_t slot0 = in ? w.queue[wf_pos(w, level, stripe, off)] : kWfHole;
+                const bool isHit = slot0 != kWfHole && (g0 & kWfMiss) != kWfMiss;
+                const bool isMiss = slot0 != kWfHole && !isHit;
+                cls |= (isHit ? 1u : (isMiss ? 2u : 0u)) << (2u * j);
+                const unsigned long long hb = __ballot(isHit), mb = __ballot(isMiss);
+                if (lane == 0) { runCnt[0][j * 4u + wave] = (uint32_t)__popcll(hb); runCnt[1][j * 4u + wave] = (uint32_t)__popcll(mb); }
             }
+            lds_barrier();
+            // ---- exclusive prefix sums over the (piece, wave) runs: wave 0 scans the hits, wave 1 the misses
+            if (wave < 2) {
+                static_assert(kShadeBatch * 4u <= 64u, "one wave scans the runs of a batch");
+                const uint32_t v = (uint32_t)lane < kShadeBatch * 4u ? runCnt[wave][lane] : 0u;
+                uint32_t incl = v;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+                    if (lane >= d) incl += up;
+                }
+                if ((uint32_t)lane < kShadeBatch * 4u) runCnt[wave][lane] = incl - v;
+                if (lane == 63) runCnt[wave][kShadeBatch * 4u] = incl;
+            }
+            lds_barrier();
+            const uint32_t nHit = runCnt[0][kShadeBatch * 4u], nLive = nHit + runCnt[1][kShadeBatch * 4u];
+#pragma unroll
+            for (uint32_t j = 0; j < kShadeBatch; j++) {
+                const uint32_t c = (cls >> (2u * j)) & 3u;
+                const unsigned long long hb = __ballot(c == 1u), mb = __ballot(c == 2u);
+                if (c == 1u) perm[runCnt[0][j * 4u + wave] + (uint32_t)__popcll(hb & below)] = (uint16_t)(j * 256u + threadIdx.x);
+                if (c == 2u) perm[nHit + runCnt[1][j * 4u + wave] + (uint32_t)__popcll(mb & below)] = (uint16_t)(j * 256u + threadIdx.x);
+            }
+            lds_barrier();
+            // ---- the waves take runs of 64 dealt entries in turn; nothing ties them together until the batch is done
+            for (uint32_t r = (uint32_t)wave * 64u; r < nLive; r += 256u) {
+                const bool mine = r + (uint32_t)lane < nLive;
+                const uint32_t off = base + (mine ? (uint32_t)perm[r + (uint32_t)lane] : 0u);
+                ShadeOut o;
+                shade_entry(a, w, level, stripe, off, mine, st, o);
+                shade_append(w, level, stripe, o);
+            }
+            lds_barrier(); // the list is rewritten by the next batch
         }
     }
     flush_stats(a, st, wgCnt);
@@ -1452,13 +1530,13 @@ void launch_render_wf(const RenderArgs& a, const WfLanes& L, int numCUs, hipStre
                 hipLaunchKernelGGL(wf_trace_packet_kernel, dim3(gridP), dim3(256), 0, stream, c, w, level, levels);
             }
             else hipLaunchKernelGGL(wf_trace_kernel, dim3(gridT), dim3(256), 0, stream, c, w, level, levels);
-            hipLaunchKernelGGL(wf_exact_kernel, dim3(gridT < RT_EXACT_GRID ? gridT : RT_EXACT_GRID), dim3(256), 0, stream, c, w, level, levels);
-            hipLaunchKernelGGL(wf_shade_kernel, dim3(gridS), dim3(256), 0, stream, c, w, level);
+            if (level == 0) hipLaunchKernelGGL((wf_shade_kernel<false>), dim3(gridS), dim3(256), 0, stream, c, w, level);
+            else hipLaunchKernelGGL((wf_shade_kernel<true>), dim3(gridS), dim3(256), 0, stream, c, w, level);
         }
         hipLaunchKernelGGL((wf_resolve_kernel<0>), dim3((w.nPix + 255u) / 256u), dim3(256), 0, stream, c, w);
         // the pixels this chunk flagged, one lane per sample; both launches exit at once when there is none
         uint32_t gridR = (w.nSlots + 255u) / 256u;
-        if (gridR > (uint32_t)numCUs * 4u) gridR = (uint32_t)numCUs * 4u;
+        if (gridR > (uint32_t)numCUs * 2u) gridR = (uint32_t)numCUs * 2u; // 2 workgroups per CU is what its 222 VGPRs admit; the loop strides
         hipLaunchKernelGGL(wf_redo_kernel, dim3(gridR), dim3(256), 0, stream, c, w);
         hipLaunchKernelGGL((wf_resolve_kernel<1>), dim3(gridR > 64u ? 64u : gridR), dim3(256), 0, stream, c, w);
     }

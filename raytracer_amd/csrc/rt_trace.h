@@ -618,8 +618,10 @@ __device__ __forceinline__ Hit trace_bvh(const SceneView& s, Ray& ray, Stack& st
 
     if (best.gid == kNoHit) return best;
     const float limit = best.t + band_of(best.t, rayScale, s.bandRel);
-    if (otherT <= limit) {
+    if (otherT <= limit) { // first the one-walk replay on a two-object table, then the general emulation
         slowPath++;
+        Hit out;
+        if (trace_band_table(s, ray, best.t, stack, cnt, out)) return out;
         return trace_bvh_exact(s, ray, q, br, __builtin_fminf(limit, m0), stack, cnt);
     }
     ray.maxDist = best.t;

@@ -15,7 +15,7 @@ passes=(
 )
 i=0
 for p in "${passes[@]}"; do
-  timeout -s KILL 180 rocprofv3 --pmc $p --output-format csv -d $R/$out/pass$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $R/$out/pass$i.log 2>&1 || { echo "pass $i failed"; tail -3 $R/$out/pass$i.log; exit 1; }
+  timeout -s KILL 180 rocprofv3 --pmc $p --output-format csv -d $R/$out/pass$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --also '' "$@" > $R/$out/pass$i.log 2>&1 || { echo "pass $i failed"; tail -3 $R/$out/pass$i.log; exit 1; }
   i=$((i+1))
 done
 python3 $R/tools/pmc_summary.py $R/$out
