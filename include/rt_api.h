@@ -187,7 +187,8 @@ int rt_event_elapsed_ms(rt_ctx* ctx, int slot_begin, int slot_end, float* ms);
 
 /* test tap: evaluate the pinned device math on n host floats.
  * op: 0 log, 1 cos, 2 exp, 3 pow(x,5), 4 pow(x,1000), 5 rsqrt, 6 random_value(seed bits), 7 byte/255 (input = byte as
- * integer bits), 8 exhaustive check of the 32-bit -> [0,1] conversion (input = high 16 bits; output = mismatch count) */
+ * integer bits), 8 exhaustive check of the 32-bit -> [0,1] conversion (input = high 16 bits; output = mismatch count), 9 exhaustive check of the
+ * pow(x,5) / pow(x,1000) shortcuts of the shading code against ops 3 / 4 (input = high 16 bits of x; output = mismatch count) */
 int rt_detmath_eval(rt_ctx* ctx, int op, const float* in, int32_t n, float* out);
 
 const char* rt_version(void);

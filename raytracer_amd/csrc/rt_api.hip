@@ -265,6 +265,18 @@ __global__ void detmath_kernel(int op, const float* __restrict__ in, int n, floa
         r = (float)bad;
         break;
     }
+    case 9: { // pow_f(x, 5) against pow5_f, and pow1000_f against pow_f(x, 1000): input = top 16 bits of x; result = mismatches
+        const uint32_t hi = __float_as_uint(x) << 16;
+        uint32_t bad = 0;
+        for (uint32_t lo = 0; lo < 65536u; lo++) {
+            const float v = __uint_as_float(hi | lo);
+            if (!(v >= 0.0f && v <= 1.0f)) continue;
+            bad += __float_as_uint(rtd::pow_f(v, 5.0f)) != __float_as_uint(rtd::pow5_f(v)) ? 1u : 0u;
+            bad += __float_as_uint(rtd::pow_f(v, 1000.0f)) != __float_as_uint(rtd::pow1000_f(v)) ? 65536u : 0u;
+        }
+        r = (float)bad;
+        break;
+    }
     default: {
         uint32_t seed = __float_as_uint(x);
         seed = seed * 747796405u + 2891336453u;
@@ -961,7 +973,7 @@ int rt_event_elapsed_ms(rt_ctx* c, int a, int b, float* ms)
 int rt_detmath_eval(rt_ctx* c, int op, const float* in, int32_t n, float* out)
 {
     RT_BIND(c);
-    if (op < 0 || op > 8 || n < 0 || (n > 0 && (!in || !out))) return fail(c, RT_ERR_INVALID, "bad detmath request");
+    if (op < 0 || op > 9 || n < 0 || (n > 0 && (!in || !out))) return fail(c, RT_ERR_INVALID, "bad detmath request");
     if (n == 0) return RT_OK;
     float *di = nullptr, *dout = nullptr;
     RT_CHECK(c, hipMalloc((void**)&di, 4 * (size_t)n));

@@ -154,6 +154,29 @@ __device__ __forceinline__ float pow_f(float x, float y)
     return (float)exp_core(p);
 }
 
+// pow_f(x, 1000.0f) for the sun term (GPURaytracer.cu:15), same bits: for 0 <= x <= 0.9f the definition above returns 0
+// (1000 * ln(0.9f) = -105.4 < -104, and log_core errs by 1e-16), so a ray that points more than 25.8 degrees away from the
+// sun skips both binary64 series; a wave of camera rays that all miss away from the sun never runs them.
+__device__ __forceinline__ float pow1000_f(float x)
+{
+    if (x <= 0.9f) return 0.0f;   // x is fmax_f(0, .): never negative, never NaN
+    return pow_f(x, 1000.0f);
+}
+
+// pow_f(x, 5.0f) for Schlick's term (:643), same bits, without the two binary64 series: x^5 by three binary64
+// products is within 2 ulp64 of the exact power, as the definition's exp(5 ln x) is within a few, so the two round
+// to the same binary32 unless the value sits within ~2^-47 (relative) of a binary32 rounding boundary; that case
+// (about one input in 10^6) and results near the binary32 subnormals, where the boundary sits elsewhere, take the
+// definition itself.  Checked against pow_f(x, 5.0f) for every binary32 in [0, 1] on the GPU (rt_detmath_eval op 9).
+__device__ __forceinline__ float pow5_f(float x)
+{
+    const double d = (double)x, d2 = d * d, p = (d2 * d2) * d;
+    const uint32_t frac = (uint32_t)f64_bits(p) & 0x1FFFFFFFu;   // the 29 bits below a binary32 mantissa
+    const uint32_t dist = frac > 0x10000000u ? frac - 0x10000000u : 0x10000000u - frac;
+    if (!(x >= 0.0f && x <= 1.0f) || dist < 4096u || p < 0x1p-120) return pow_f(x, 5.0f);
+    return (float)p;
+}
+
 // b / 255.0f, correctly rounded, for a byte b -- the texel conversion (Material.cu:199-206 divides on the host;
 // here the texels stay RGBA8 and every tap converts).  q = b * fl(1/255) is within an ulp; one residual step
 // r = fma(-255, q, b), q + r * fl(1/255) lands on the correctly rounded quotient for all 256 bytes (checked

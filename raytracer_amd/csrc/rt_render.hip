@@ -131,7 +131,7 @@ __device__ __forceinline__ V4 tex2d_rays(const float4* __restrict__ tab, int w, 
 __device__ __forceinline__ V4 sky_light(const V4& dir, const RenderArgs& a)
 {
     const V4 l = mk4(a.skyDir[0], a.skyDir[1], a.skyDir[2], a.skyDir[3]);
-    const float sun = rtd::pow_f(rtd::fmax_f(0.0f, dot3(dir, l)), 1000.0f) * a.lightColor[3];
+    const float sun = rtd::pow1000_f(rtd::fmax_f(0.0f, dot3(dir, l))) * a.lightColor[3];
     return mk4(a.skyColor[0] * a.skyColor[3] + a.lightColor[0] * sun, a.skyColor[1] * a.skyColor[3] + a.lightColor[1] * sun,
                a.skyColor[2] * a.skyColor[3] + a.lightColor[2] * sun, 1.0f);
 }
@@ -324,7 +324,7 @@ __device__ __forceinline__ bool shade_segment(const RenderArgs& a, const Hit& h,
     const float ndl = rtd::fmax_f(dot3(N, L), 0.0f);
     const float G = geometry_schlick(ndv, sf.roughness) * geometry_schlick(ndl, sf.roughness);
     const float cosT = rtd::fmax_f(dot3(H, V), 0.0f);
-    const float pw = rtd::pow_f(1.0f - rtd::fmin_f(cosT, 1.0f), 5.0f);
+    const float pw = rtd::pow5_f(1.0f - rtd::fmin_f(cosT, 1.0f));
     const float Fx = F0.x + (1.0f - F0.x) * pw, Fy = F0.y + (1.0f - F0.y) * pw, Fz = F0.z + (1.0f - F0.z) * pw;
 
     const float mc = 1.0f - sf.metal;

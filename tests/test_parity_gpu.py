@@ -402,6 +402,10 @@ def test_detmath_matches_oracle_bit_for_bit(ctx):
     assert np.array_equal(ctx.detmath(7, b.view(np.float32)), (b.astype(np.float32) / np.float32(255.0)))
     hi = np.arange(65536, dtype=np.uint32)
     assert ctx.detmath(8, hi.view(np.float32)).sum() == 0.0
+    # the two shortcuts of the shading code against the definitions they stand for, for every binary32 in [0, 1]:
+    # pow5_f == pow_f(x, 5) (Schlick's term) and pow1000_f == pow_f(x, 1000) (the sun term)
+    hi01 = np.arange(0, 0x3F81, dtype=np.uint32)
+    assert ctx.detmath(9, hi01.view(np.float32)).sum() == 0.0
     seeds = rng.integers(0, 2**32, 50000, dtype=np.uint64).astype(np.uint32)
     got = ctx.detmath(6, seeds.view(np.float32))
     import ctypes as C
