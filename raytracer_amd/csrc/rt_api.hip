@@ -198,6 +198,7 @@ size_t wf_carve(uint8_t* base, size_t slots, int levels, rt::WfBufs& w)
     w.pixFlag = (uint32_t*)take(4 * ((slots + 63) & ~(size_t)63));
     w.redoList = (uint32_t*)take(4 * ((slots + 63) & ~(size_t)63));
     w.queue = (uint32_t*)take(4 * queueWords);
+    w.exactList = (uint32_t*)take(4 * (queueWords / 2));
     w.ctrl = (uint32_t*)take(4 * rt::wf_ctrl_words(levels));
     return off;
 }

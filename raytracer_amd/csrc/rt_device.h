@@ -113,6 +113,12 @@ struct SceneView {
 // One slot per sample of a chunk of 8x8 pixel tiles: slot = pixelInChunk * spp + sampleIndex.
 // Per bounce level L a queue lists the slots whose path is still alive; it is cut into kWfStripes
 // sub-queues with their own counts and cursors (a single hot counter saturates at ~88 atomics/us).
+#ifndef RT_EXACT_PASS
+#define RT_EXACT_PASS 1   // 1: the tie-band rays of a level are listed and traced again by wf_exact before the level is shaded;
+#endif                    // 0: they flag their pixel for the redo launch instead (four launches per frame fewer, every flagged pixel's samples redone)
+#ifndef RT_EXACT_GRID
+#define RT_EXACT_GRID 128u
+#endif
 constexpr int kWfStripes = 64;
 constexpr int kWfCtrlStride = 32;          // words between two counters (one 128-byte line each)
 constexpr uint32_t kWfHole = 0xFFFFFFFFu;  // queue entry without a path
@@ -134,7 +140,8 @@ struct WfBufs {
     uint32_t* pixFlag;   // [pixelInChunk] != 0: flagged for the redo launch
     uint32_t* redoList;  // [pixelInChunk] the chunk's flagged pixels (a lane's chunks run one after the other, so they share it)
     uint32_t* queue;     // [2][kWfStripes][subCap] slots, ping-pong over levels
-    uint32_t* ctrl;      // [level][2][kWfStripes][kWfCtrlStride]: counts, cursors; then the redo count
+    uint32_t* exactList; // [kWfStripes][subCap] hit positions of the level's rays inside the tie band, listed per stripe (RT_EXACT_PASS)
+    uint32_t* ctrl;      // [level][2][kWfStripes][kWfCtrlStride]: counts, cursors; then the redo count; then per level one tie-band count per stripe
     uint32_t subCap;
     uint32_t nSlots;
     uint32_t nPix;       // pixels of the chunk = tiles * 64 (edge tiles include pixels outside the rectangle)
@@ -145,7 +152,11 @@ struct WfBufs {
 // words of WfBufs::ctrl for `levels` bounce levels, and where the two kinds of single counters sit in it
 __host__ __device__ inline size_t wf_ctrl_words(int levels)
 {
-    return (size_t)(levels + 1) * 2 * kWfStripes * kWfCtrlStride + (size_t)kWfCtrlStride;
+    return (size_t)(levels + 1) * 2 * kWfStripes * kWfCtrlStride + (size_t)(1 + levels * kWfStripes) * kWfCtrlStride;
+}
+__host__ __device__ inline size_t wf_ctrl_exact(int levels, int level, int stripe)
+{
+    return (size_t)(levels + 1) * 2 * kWfStripes * kWfCtrlStride + (size_t)(1 + level * kWfStripes + stripe) * kWfCtrlStride;
 }
 __host__ __device__ inline size_t wf_ctrl_redo(int levels) { return (size_t)(levels + 1) * 2 * kWfStripes * kWfCtrlStride; }
 struct RenderArgs {

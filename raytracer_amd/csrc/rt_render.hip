@@ -285,7 +285,9 @@ __device__ __forceinline__ bool shade_segment(const RenderArgs& a, const Hit& h,
         return false;
     }
     uint32_t ho, hm, ht;
+#ifndef RT_DIAG_EXACT
     st.hits++;
+#endif
 #ifndef RT_ABLATE_CULL
     if (cullObj != kNoHit) {
         const ObjCull o = load_obj(a.scene.objects + cullObj);
@@ -932,6 +934,13 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
             const bool over = stack.dropped;
             stack.dropped = false;
             if (band) st.slow++;
+#if RT_EXACT_PASS
+            if (band) { // listed under the stripe the ray sits in: that list cannot overflow
+                const uint32_t bs = hitPos / w.subCap;
+                w.exactList[(size_t)bs * w.subCap + atomicAdd(w.ctrl + wf_ctrl_exact(levels, level, (int)bs), 1u)] = hitPos;
+                band = false;
+            }
+#endif
             w.hitA[hitPos] = make_float4(h.t, h.b0, h.b1, h.b2);
             w.hitM[hitPos] = make_uint2((h.gid == kNoHit ? kWfMiss : h.gid) | (over || band ? kWfDanger : 0u), T.bestObj);
             have = false;
@@ -1135,6 +1144,12 @@ __global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const R
             const Hit hres = trav_result(T, ray, band);
             const uint32_t hitPos = (uint32_t)wf_hit_pos(w, blockStripe, off + (uint32_t)lane);
             if (band) st.slow++;
+#if RT_EXACT_PASS
+            if (band) {
+                w.exactList[(size_t)blockStripe * w.subCap + atomicAdd(w.ctrl + wf_ctrl_exact(levels, level, (int)blockStripe), 1u)] = hitPos;
+                band = false;
+            }
+#endif
             w.hitA[hitPos] = make_float4(hres.t, hres.b0, hres.b1, hres.b2);
             w.hitM[hitPos] = make_uint2((hres.gid == kNoHit ? kWfMiss : hres.gid) | (overflow || band ? kWfDanger : 0u), T.bestObj);
         }
@@ -1152,6 +1167,61 @@ __global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const R
     }
     flush_stats(a, st, wgCnt);
 }
+
+#if RT_EXACT_PASS
+// The rays of a level whose closest hit depends on the reference's object order (another object's hit
+// inside the tie band): traced again with the exact in-order emulation inline, one
+// lane per ray, between the level's trace and shade launches.  Exits at once when the list is empty.
+__global__ __launch_bounds__(256) void wf_exact_kernel(const RenderArgs a, const WfBufs w, const int level, const int levels)
+{
+    __shared__ uint32_t ldsStack[kLdsStack * kBlock];
+    __shared__ uint32_t wgCnt[8];
+    uint32_t ovf[kStackDepth - kLdsStack];
+    Stack stack; stack.lds = ldsStack + threadIdx.x; stack.ovf = ovf;
+    LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
+    // the stripes' lists read as one: entry i belongs to the last stripe whose running total is <= i
+    __shared__ uint32_t listBase[kWfStripes + 1];
+    if (threadIdx.x < 64) {
+        const uint32_t cnt = w.ctrl[wf_ctrl_exact(levels, level, (int)threadIdx.x)];
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+            if ((int)threadIdx.x >= d) incl += up;
+        }
+        listBase[threadIdx.x + 1] = incl;
+        if (threadIdx.x == 0) listBase[0] = 0u;
+    }
+    __syncthreads();
+    const uint32_t n = listBase[kWfStripes];
+    const size_t half = (size_t)(level & 1) * kWfStripes * (size_t)w.subCap;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        uint32_t ls = 0;
+#pragma unroll
+        for (uint32_t step = kWfStripes / 2; step > 0; step >>= 1)
+            if (listBase[ls + step] <= i) ls += step;
+        const uint32_t hp = w.exactList[(size_t)ls * w.subCap + (i - listBase[ls])];
+        const float4 o = wf_ray_origin(a, w, level, half + hp), d = w.rayD[half + hp];
+        Ray ray; ray.ox = o.x; ray.oy = o.y; ray.oz = o.z; ray.maxDist = o.w; ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
+        Hit h;
+        if (!trace_band_table(a.scene, ray, w.hitA[hp].x, stack, st.bvh, h)) {
+            bool unused = false;
+            h = closest_hit<3>(a.scene, ray, stack, st, unused);
+#ifdef RT_DIAG_EXACT
+            st.hits++; // diagnostic build: table fallbacks are reported as shaded hits
+#endif
+        }
+        w.hitA[hp] = make_float4(h.t, h.b0, h.b1, h.b2);
+        const uint32_t hobj = h.gid != kNoHit ? a.scene.triRef[h.gid].obj : kNoHit;
+        w.hitM[hp] = make_uint2((h.gid == kNoHit ? kWfMiss : h.gid) | (w.hitM[hp].x & kWfDanger), hobj);
+    }
+    st.rays = 0; st.slow = 0; // queries are counted per finished sample, tie-band rays by wf_trace
+#ifdef RT_DIAG_EXACT
+    st.bvh.nodes = 0; st.bvh.tris = 0;
+#endif
+    flush_stats(a, st, wgCnt);
+}
+#endif
 
 // material evaluation, BRDF and bounce ray of one level (:172-242): one lane per live path.
 //
@@ -1530,6 +1600,9 @@ void launch_render_wf(const RenderArgs& a, const WfLanes& L, int numCUs, hipStre
                 hipLaunchKernelGGL(wf_trace_packet_kernel, dim3(gridP), dim3(256), 0, stream, c, w, level, levels);
             }
             else hipLaunchKernelGGL(wf_trace_kernel, dim3(gridT), dim3(256), 0, stream, c, w, level, levels);
+#if RT_EXACT_PASS
+            hipLaunchKernelGGL(wf_exact_kernel, dim3(gridT < RT_EXACT_GRID ? gridT : RT_EXACT_GRID), dim3(256), 0, stream, c, w, level, levels);
+#endif
             if (level == 0) hipLaunchKernelGGL((wf_shade_kernel<false>), dim3(gridS), dim3(256), 0, stream, c, w, level);
             else hipLaunchKernelGGL((wf_shade_kernel<true>), dim3(gridS), dim3(256), 0, stream, c, w, level);
         }

@@ -511,12 +511,12 @@ __device__ __noinline__ Hit trace_bvh_exact(const SceneView& s, Ray& ray, const 
 
 // The same emulation in one walk, for a ray already known to sit in the tie band (wf_exact); tBest is the
 // distance of the closest hit that the band-free traversal found, without any object cull.  The walk,
-// bounded by the band limit, keeps per object the closest hit accepted under m0 -- two objects fit: the
-// floor under a bin, a sphere sunk into the terrain -- and the reference's loop over the objects in id
+// bounded by the band limit, keeps per object the closest hit accepted under m0 -- kBandObjects objects fit: the
+// floor under a bin, a sphere sunk into the terrain, neighbouring piles leaning into each other -- and the reference's loop over the objects in id
 // order (:247-265) is replayed on that table: an object's closest hit under a smaller maxDistance m is
 // the same triangle as long as that triangle is still accepted (acceptance is monotone in m), and no hit
 // at all when its distance exceeds m.  Returns false, and the caller runs the full emulation above, when
-//   - a third object has a hit inside the limit,
+//   - more than kBandObjects objects have a hit inside the limit,
 //   - a hit's object fails its cull under m0 (tBest may then not be the closest accepted hit), or
 //   - a table hit lies within m but the reference's pre-filter (tScaled against m * det) rejects it:
 //     another triangle of that object could then be the one the reference finds.
@@ -525,6 +525,7 @@ struct BandEntry {
     Hit h;
     float ts, det;
 };
+constexpr int kBandObjects = 4;   // objects the table holds: a floor, the pile standing on it and two neighbours leaning into it
 
 __device__ __forceinline__ bool trace_band_table(const SceneView& s, Ray& ray, float tBest, Stack& stack, BvhCounters& cnt,
                                                  Hit& out)
@@ -535,11 +536,13 @@ __device__ __forceinline__ bool trace_band_table(const SceneView& s, Ray& ray, f
                                            __builtin_fmaxf(__builtin_fabsf(ray.oz), s.sceneMaxAbs));
     const float m0 = ray.maxDist;
     const float limit = __builtin_fminf(tBest + band_of(tBest, rayScale, s.bandRel), m0);
-    BandEntry e0, e1;
-    e0.obj = e1.obj = kNoHit;
-    e0.h.t = e1.h.t = FLT_MAX; e0.h.gid = e1.h.gid = kNoHit;
-    e0.h.b0 = e0.h.b1 = e0.h.b2 = e1.h.b0 = e1.h.b1 = e1.h.b2 = 0.0f;
-    e0.ts = e0.det = e1.ts = e1.det = 0.0f;
+    BandEntry e[kBandObjects];
+#pragma unroll
+    for (int k = 0; k < kBandObjects; k++) {
+        e[k].obj = kNoHit;
+        e[k].h.t = FLT_MAX; e[k].h.gid = kNoHit; e[k].h.b0 = e[k].h.b1 = e[k].h.b2 = 0.0f;
+        e[k].ts = e[k].det = 0.0f;
+    }
     bool ok = true;
     CullCache cc; cc.obj = kNoHit; cc.tmin = 0.0f; cc.bfar = 0.0f;
     bvh_walk(s, br, q, limit, stack, cnt, [&](const float4& A, const float4& B, const float4& C, float bound) {
@@ -547,32 +550,41 @@ __device__ __forceinline__ bool trace_band_table(const SceneView& s, Ray& ray, f
         if (!tri_test_rot(q, m0, A, B, C, t, b0, b1, b2, &ts, &det) || t > limit) return bound;
         const uint32_t gid = __float_as_uint(A.w), obj = __float_as_uint(B.w);
         cull_lookup(s, ray, obj, cc);
-        auto keep = [&](BandEntry& e) {
-            e.obj = obj;
-            if (t < e.h.t || (t == e.h.t && gid < e.h.gid)) {
-                e.h.t = t; e.h.b0 = b0; e.h.b1 = b1; e.h.b2 = b2; e.h.gid = gid; e.ts = ts; e.det = det;
-            }
-        };
         if (!object_cull_pass(cc.tmin, cc.bfar, m0)) ok = false;
-        else if (e0.obj == kNoHit || e0.obj == obj) keep(e0);
-        else if (e1.obj == kNoHit || e1.obj == obj) keep(e1);
-        else ok = false;
+        else {
+            bool placed = false; // the entry of this object, or the first free one
+#pragma unroll
+            for (int k = 0; k < kBandObjects; k++) {
+                if (!placed && (e[k].obj == kNoHit || e[k].obj == obj)) {
+                    placed = true;
+                    e[k].obj = obj;
+                    if (t < e[k].h.t || (t == e[k].h.t && gid < e[k].h.gid)) {
+                        e[k].h.t = t; e[k].h.b0 = b0; e[k].h.b1 = b1; e[k].h.b2 = b2; e[k].h.gid = gid; e[k].ts = ts; e[k].det = det;
+                    }
+                }
+            }
+            if (!placed) ok = false;
+        }
         return ok ? bound : -1.0f; // a bound below every entry distance: the walk only drains its stack
     });
     if (!ok) return false;
-    if (e1.obj < e0.obj) { const BandEntry x = e0; e0 = e1; e1 = x; } // id order; an empty entry (kNoHit) sorts last
+    // id order, empty entries (kNoHit) last: the reference's loop over the objects (:247-265)
+#pragma unroll
+    for (int i = 0; i < kBandObjects - 1; i++)
+#pragma unroll
+        for (int k = 0; k < kBandObjects - 1 - i; k++)
+            if (e[k + 1].obj < e[k].obj) { const BandEntry x = e[k]; e[k] = e[k + 1]; e[k + 1] = x; }
     Hit best; best.t = FLT_MAX; best.gid = kNoHit; best.b0 = best.b1 = best.b2 = 0.0f;
     float m = m0;
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const BandEntry& e = k == 0 ? e0 : e1;
-        if (e.obj == kNoHit) continue;
-        cull_lookup(s, ray, e.obj, cc);
+    for (int k = 0; k < kBandObjects; k++) {
+        if (e[k].obj == kNoHit) continue;
+        cull_lookup(s, ray, e[k].obj, cc);
         if (!object_cull_pass(cc.tmin, cc.bfar, m)) continue;
-        if (e.h.t > m) continue;
-        const float md = m * e.det;
-        if (e.det < 0 ? e.ts < md : e.ts > md) return false;
-        if (e.h.t < best.t) { best = e.h; m = e.h.t; }
+        if (e[k].h.t > m) continue;
+        const float md = m * e[k].det;
+        if (e[k].det < 0 ? e[k].ts < md : e[k].ts > md) return false;
+        if (e[k].h.t < best.t) { best = e[k].h; m = e[k].h.t; }
     }
     ray.maxDist = m;
     out = best;

@@ -3,7 +3,8 @@
 extra=$1; shift
 for lib in "$@"; do
   if [ -n "$lib" ]; then export RT_AMD_LIB=$PWD/raytracer_amd/$lib; else unset RT_AMD_LIB; fi
-  tag=lvl_$(echo "${lib:-default}" | tr -c 'A-Za-z0-9_\n' '_')
+  tag=lvl_$(echo "${lib:-default}_$extra" | tr -c 'A-Za-z0-9_\n' '_')
+  rm -rf gpurun_out/ks_$tag
   echo "== ${lib:-default} $extra"
   bash tools/kstats.sh $tag $extra | grep -E "start|span" | awk '{printf "%s %s | ", substr($1,5,18), $(NF-1)} END {print ""}'
 done
