@@ -87,6 +87,90 @@ int main(int argc, char** argv)
         } catch (const std::exception& e) { fprintf(stderr, "error: %s\n", e.what()); return 2; }
         return 0;
     }
-    fprintf(stderr, "usage: rt_headless math | render OUT.png OUT.f32 W H SPP DEPTH\n");
+    if (argc >= 3 && std::string(argv[1]) == "decode") {
+        // the host mirror's PNG decoder on a file: extents, channels and a CRC of the decoded bytes (CPU only)
+        std::vector<unsigned char> pix; int w = 0, h = 0, n = 0;
+        if (!png::decode(argv[2], pix, w, h, n)) { printf("refused\n"); return 0; }
+        printf("%d %d %d %lu\n", w, h, n, (unsigned long)crc32(0L, pix.data(), (uInt)pix.size()));
+        return 0;
+    }
+    auto build_c1 = [](Device& dev, Scene& scene, std::shared_ptr<Material>& def) {
+        def = std::make_shared<Material>(dev, "Default", vec4{ 0.5f, 0.5f, 0.5f, 1.0f }, 0.5f, 0.0f);
+        def->sendToGPU();
+        auto cube = std::make_shared<Cube>(dev);
+        cube->setMaterial(def);
+        auto sphere = std::make_shared<Sphere>(dev, vec3{ 1.5f, 0.0f, 0.0f });
+        sphere->setMaterial(def);
+        cube->sendToGPU(); sphere->sendToGPU();
+        scene.addToScene("cube", cube);
+        scene.addToScene("sphere", sphere);
+    };
+    if (argc >= 6 && std::string(argv[1]) == "frames") {
+        // GPURaytracer::raytrace's counter rule (GPURaytracer.cu:69-73) over seven frames -- progressive rendering on for
+        // three, off for two, on for two -- each frame appended to OUT.f32; then path-keyed sharing of Textures and CustomModels
+        try {
+            const int W = atoi(argv[3]), H = atoi(argv[4]);
+            Device dev(0);
+            Scene scene(dev); std::shared_ptr<Material> def;
+            build_c1(dev, scene, def);
+            Camera cam(dev, vec3{ 0.6f, 0.3f, 4.0f }, quat{}, 45.0f, 1.0f);
+            cam.setWidth(W); cam.setHeight(H);
+            GPURaytracer rt(dev);
+            rt.setBounceCount(3); rt.setSampleCount(2);
+            FrameBuffer fb(dev, W, H);
+            FILE* f = fopen(argv[2], "wb");
+            if (!f) return 6;
+            const bool plan[7] = { true, true, true, false, false, true, true };
+            for (bool prog : plan) {
+                rt.setProgressiveRendering(prog);
+                rt.raytrace(scene, cam, fb);
+                const std::vector<float> px = fb.read();
+                if (fwrite(px.data(), 4, px.size(), f) != px.size()) return 6;
+            }
+            fclose(f);
+            // sharing: two Textures of one path upload once; two CustomModels of one path parse and upload once
+            fb.savePNG(argv[5]);
+            {
+                Texture a(dev, argv[5]), b(dev, argv[5]);
+                if (!a.getLoadSuccess() || a.id() != b.id() || dev.textureUploads != 1) return 10;
+            }
+            { Texture c(dev, argv[5]); if (dev.textureUploads != 2) return 11; } // the last owner gone: loaded again
+            if (argc >= 7) {
+                CustomModel m1(dev, argv[6]), m2(dev, argv[6], vec3{ 1, 0, 0 });
+                if (!m1.getLoadSuccess() || !m2.getLoadSuccess() || dev.modelParses != 1) return 12;
+                if (m1.getMeshes()[0].first->id() != m2.getMeshes()[0].first->id()) return 13;
+            }
+            printf("ok frames\n");
+        } catch (const std::exception& e) { fprintf(stderr, "error: %s\n", e.what()); return 2; }
+        return 0;
+    }
+    if (argc >= 7 && std::string(argv[1]) == "multi") {
+        // one thread, N contexts (all on GPU 0 here): the interleaved bands of one frame, composited on the host
+        try {
+            const int W = atoi(argv[3]), H = atoi(argv[4]), spp = atoi(argv[5]), n = atoi(argv[6]);
+            std::vector<std::unique_ptr<Device>> devs; std::vector<std::unique_ptr<Scene>> scenes; std::vector<std::unique_ptr<Camera>> cams;
+            std::vector<std::unique_ptr<FrameBuffer>> fbs; std::vector<std::shared_ptr<Material>> mats((size_t)n);
+            std::vector<MultiGPURaytracer::Rank> ranks;
+            for (int r = 0; r < n; r++) {
+                devs.emplace_back(new Device(0));
+                scenes.emplace_back(new Scene(*devs[r]));
+                build_c1(*devs[r], *scenes[r], mats[r]);
+                cams.emplace_back(new Camera(*devs[r], vec3{ 0.6f, 0.3f, 4.0f }, quat{}, 45.0f, 1.0f));
+                cams[r]->setWidth(W); cams[r]->setHeight(H);
+                fbs.emplace_back(new FrameBuffer(*devs[r], W, H));
+                ranks.push_back({ devs[r].get(), scenes[r].get(), cams[r].get(), fbs[r].get() });
+            }
+            MultiGPURaytracer rt(ranks, 8);
+            rt.setBounceCount(4); rt.setSampleCount(spp); rt.setFrameCount(3);
+            std::vector<float> out;
+            rt.raytrace(out);
+            FILE* f = fopen(argv[2], "wb");
+            if (!f || fwrite(out.data(), 4, out.size(), f) != out.size()) return 6;
+            fclose(f);
+            printf("ok multi %d\n", n);
+        } catch (const std::exception& e) { fprintf(stderr, "error: %s\n", e.what()); return 2; }
+        return 0;
+    }
+    fprintf(stderr, "usage: rt_headless math | asset FILE | decode FILE.png | render OUT.png OUT.f32 W H SPP DEPTH | frames OUT.f32 W H TMP.png [MODEL] | multi OUT.f32 W H SPP N\n");
     return 1;
 }

@@ -97,6 +97,10 @@ public:
     // re-committed every frame (the reference's Scene::getGPUObjectDataVector pattern)
     void setOption(int option, int value) const { check(rt_set_option(ctx_, option, value)); }
     void check(int rc) const { if (rc != RT_OK) throw std::runtime_error(std::string("librt_amd: ") + rt_last_error(ctx_)); }
+    // path-keyed sharing, per context instead of the reference's process-wide statics (textureMap, Material.cu:165-178;
+    // customModels, CustomModel.cpp:10-24): an entry lives while any Texture / CustomModel of that path does
+    std::unordered_map<std::string, std::weak_ptr<void>> textureMap, modelMap;
+    int textureUploads = 0, modelParses = 0;   // what actually reached the device / the parser (tests)
 private:
     rt_ctx* ctx_ = nullptr;
 };
@@ -192,35 +196,52 @@ inline bool decode(const std::string& path, std::vector<unsigned char>& pix, int
 // ---------------------------------------------------------------- Texture / Material (Material.hpp:17-117)
 class Texture {
 public:
-    Texture(Device& dev, const char* path) : dev_(dev), path_(path)
+    // stb_image in the reference; this mirror decodes PNG (8- and 16-bit, the latter reduced with >> 8 as stb_image.h:1198
+    // does) and refuses every other format: getLoadSuccess() is then false and Material::set*Texture returns false,
+    // which is the reference's own convention for an unreadable file (Material.cu:113-130).  JPEG (all of
+    // res/lowpolypbrtrash/textures) is among the refused: its texel bytes depend on the decoder.
+    Texture(Device& dev, const char* path) : path_(path)
     {
+        auto it = dev.textureMap.find(path_);
+        if (it != dev.textureMap.end()) if (auto live = std::static_pointer_cast<Store>(it->second.lock())) { store_ = live; return; } // already loaded: shared
+        store_ = std::make_shared<Store>(dev);
+        dev.textureMap[path_] = store_;
         std::vector<unsigned char> pix; int n = 0;
-        if (!png::decode(path_, pix, width_, height_, n)) { loadSuccess_ = false; return; } // JPEG: not decoded by this host mirror
-        upload(pix.data(), n);
+        if (!png::decode(path_, pix, store_->width, store_->height, n)) return;
+        store_->upload(pix.data(), n);
     }
-    Texture(Device& dev, const unsigned char* pixels, int w, int h, int nChannels) : dev_(dev), width_(w), height_(h) { upload(pixels, nChannels); }
-    ~Texture() { if (id_ >= 0) rt_texture_destroy(dev_.ctx(), id_); }
-    Texture(const Texture&) = delete;
-    int getWidth() const { return width_; }
-    int getHeight() const { return height_; }
-    bool getLoadSuccess() const { return loadSuccess_; }
-    std::string getPath() const { return path_; }
-    rt_id id() const { return id_; }
-private:
-    void upload(const unsigned char* idata, int n)
+    Texture(Device& dev, const unsigned char* pixels, int w, int h, int nChannels) : store_(std::make_shared<Store>(dev))
     {
-        // 4-channel expansion with the reference's quirk (Material.cu:184-197): G,B = following bytes
-        const size_t np = (size_t)width_ * height_, total = np * n;
-        std::vector<unsigned char> rgba(np * 4);
-        auto at = [&](size_t k) -> unsigned char { return k < total ? idata[k] : 0; };
-        for (size_t i = 0; i < np; i++) { rgba[i * 4] = at(i * n); rgba[i * 4 + 1] = at(i * n + 1); rgba[i * 4 + 2] = at(i * n + 2); rgba[i * 4 + 3] = n == 4 ? at(i * n + 3) : 255; }
-        loadSuccess_ = rt_texture_create(dev_.ctx(), rgba.data(), width_, height_, &id_) == RT_OK;
+        store_->width = w; store_->height = h;
+        store_->upload(pixels, nChannels);
     }
-    Device& dev_;
+    Texture(const Texture&) = delete;
+    int getWidth() const { return store_->width; }
+    int getHeight() const { return store_->height; }
+    bool getLoadSuccess() const { return store_->loadSuccess; }
+    std::string getPath() const { return path_; }
+    rt_id id() const { return store_->id; }
+private:
+    struct Store { // the device texture the Textures of one path share; freed with the last of them (ref count, Material.cu:234-252)
+        explicit Store(Device& d) : dev(d) {}
+        ~Store() { if (id >= 0) rt_texture_destroy(dev.ctx(), id); }
+        void upload(const unsigned char* idata, int n)
+        {
+            // 4-channel expansion with the reference's quirk (Material.cu:184-197): G,B = following bytes
+            const size_t np = (size_t)width * height, total = np * n;
+            std::vector<unsigned char> rgba(np * 4);
+            auto at = [&](size_t k) -> unsigned char { return k < total ? idata[k] : 0; };
+            for (size_t i = 0; i < np; i++) { rgba[i * 4] = at(i * n); rgba[i * 4 + 1] = at(i * n + 1); rgba[i * 4 + 2] = at(i * n + 2); rgba[i * 4 + 3] = n == 4 ? at(i * n + 3) : 255; }
+            loadSuccess = rt_texture_create(dev.ctx(), rgba.data(), width, height, &id) == RT_OK;
+            dev.textureUploads++;
+        }
+        Device& dev;
+        int width = 0, height = 0;
+        bool loadSuccess = false;
+        rt_id id = -1;
+    };
     std::string path_;
-    int width_ = 0, height_ = 0;
-    bool loadSuccess_ = false;
-    rt_id id_ = -1;
+    std::shared_ptr<Store> store_;
 };
 
 class Material {
@@ -415,6 +436,17 @@ public:
     CustomModel(Device& dev, const std::string& path, vec3 position = {}, quat rotation = {}, vec3 scl = { 1, 1, 1 })
         : MeshObject(dev, {}, {}, position, rotation, scl), path_(path)
     {
+        auto it = dev.modelMap.find(path);
+        if (it != dev.modelMap.end()) if (auto live = std::static_pointer_cast<Data>(it->second.lock())) {
+            data_ = live;   // copyHostLLData (CustomModel.cpp:10-19): the same Mesh and Material objects, nothing parsed or uploaded
+            meshes = data_->meshes; materials = data_->materials;
+            isComposite = meshes.size() > 1;
+            if (!meshes.empty()) { updateCompositeBounds(); loadSuccess = true; }
+            return;
+        }
+        data_ = std::make_shared<Data>();
+        dev.modelMap[path] = data_;
+        dev.modelParses++;
         assets::FlatAsset a;
         if (!assets::loadAsset(path, a)) return;
         const std::string dir = a.textureDirectory();
@@ -437,12 +469,15 @@ public:
             if (fm.indices.empty()) continue;
             meshes.emplace_back(std::make_shared<Mesh>(dev, fm.positions, fm.indices, fm.uvs, fm.normals), fm.material);
         }
+        data_->meshes = meshes; data_->materials = materials;
         isComposite = meshes.size() > 1;
         if (!meshes.empty()) { updateCompositeBounds(); loadSuccess = true; }
     }
     std::string getPath() const { return path_; }
 private:
+    struct Data { std::vector<std::pair<std::shared_ptr<Mesh>, int>> meshes; std::vector<std::shared_ptr<Material>> materials; };
     std::string path_;
+    std::shared_ptr<Data> data_;
 };
 
 // ---------------------------------------------------------------- Scene (Scene.hpp:41-176, Scene.cpp:3-29); iteration = insertion order
@@ -604,6 +639,50 @@ public:
     }
 private:
     Device& dev_;
+};
+
+// ---------------------------------------------------------------- one host thread driving N contexts (SURVEY 8b "Threading", 8e)
+// The image-tile split of one frame in C++: every context (one per GPU; several on one GPU work too) holds its own
+// copy of the scene, rank r renders the interleaved row bands r, r + N, ... of the frame with ONE asynchronous
+// rt_render_bands call on its own stream, the thread then waits for all of them and composites on the host.
+// (Between GPUs of a node the composite is an RCCL all_gather instead: raytracer_amd/multigpu.py, bench.py.)
+class MultiGPURaytracer : public Raytracer {
+public:
+    struct Rank { Device* dev; Scene* scene; Camera* camera; FrameBuffer* fb; };
+    explicit MultiGPURaytracer(std::vector<Rank> ranks, int bandRows = 16) : ranks_(std::move(ranks)), bandRows_(bandRows) {}
+    // out: W*H*4 floats, row 0 = bottom, as rt_framebuffer_read gives them
+    void raytrace(std::vector<float>& out, bool recommit = true)
+    {
+        const int n = (int)ranks_.size();
+        const int W = ranks_[0].camera->getWidth(), H = ranks_[0].camera->getHeight();
+        for (int r = 0; r < n; r++) { // enqueue everywhere first: the contexts' streams run side by side
+            Rank& k = ranks_[r];
+            if (recommit) k.scene->commit();
+            k.camera->update();
+            rt_camera_params cam; const vec3 p = k.camera->getPosition(); const quat q = k.camera->getRotation();
+            cam.origin[0] = p.x; cam.origin[1] = p.y; cam.origin[2] = p.z; cam.origin[3] = 1.0f;
+            cam.rotation[0] = q.x; cam.rotation[1] = q.y; cam.rotation[2] = q.z; cam.rotation[3] = q.w;
+            cam.exposure = k.camera->getExposure(); cam.width = W; cam.height = H;
+            rt_renderer_params rp{ bounceCount, maxDistance, aoIntensity, frameCount, progressiveFrameCount, antiAliasingEnabled ? 1 : 0, sampleCount };
+            rt_sky_params sky;
+            const vec4* src[3] = { &lightDirection, &lightColor, &skyColor }; float* dst[3] = { sky.direction, sky.lightColor, sky.skyColor };
+            for (int i = 0; i < 3; i++) { dst[i][0] = src[i]->x; dst[i][1] = src[i]->y; dst[i][2] = src[i]->z; dst[i][3] = src[i]->w; }
+            k.dev->check(rt_render_bands(k.dev->ctx(), &cam, &rp, &sky, rt_rect{ 0, 0, W, H }, bandRows_, r, n, k.fb->id()));
+        }
+        out.assign((size_t)W * H * 4, 0.0f);
+        for (int r = 0; r < n; r++) { // wait + composite: band b belongs to rank b % n
+            const std::vector<float> part = ranks_[r].fb->read();
+            for (int y0 = r * bandRows_; y0 < H; y0 += n * bandRows_) {
+                const int y1 = std::min(H, y0 + bandRows_);
+                memcpy(&out[(size_t)y0 * W * 4], &part[(size_t)y0 * W * 4], (size_t)(y1 - y0) * W * 16);
+            }
+        }
+        frameCount++;
+        if (progressiveRendering) progressiveFrameCount++; else progressiveFrameCount = 0;
+    }
+private:
+    std::vector<Rank> ranks_;
+    int bandRows_;
 };
 
 } // namespace rth

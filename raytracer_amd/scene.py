@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import math
 import os
+import weakref
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -50,20 +51,41 @@ def expand_to_rgba8(img: np.ndarray) -> np.ndarray:
     return out.reshape(h, w, 4)
 
 
+class _TexelStore:
+    """The decoded image several Texture objects of one path share (the reference's textureMap entry,
+    src/Material.cu:165-178): `rgba8` is uploaded once per FlatScene, whatever the number of Textures."""
+
+    def __init__(self):
+        self.rgba8: Optional[np.ndarray] = None
+        self.loadSuccess = False
+
+
+_TEXTURE_MAP = weakref.WeakValueDictionary()  # path -> _TexelStore, alive while any Texture of that path is (ref count, :234-252)
+TEXTURE_DECODES = 0                           # files actually decoded (tests: two loads of one path decode once)
+
+
 class Texture:
-    """src/Material.hpp:17-50.  `Texture(path)` decodes with PIL (the reference uses
-    stb_image; PNG texel bytes are identical, JPEG decoders may differ by +-1) or wraps an
-    already decoded HxWxC uint8 array."""
+    """src/Material.hpp:17-50.  `Texture(path)` decodes with PIL (the reference uses stb_image: PNG texel
+    bytes are identical -- PNG is lossless, and a 16-bit PNG is reduced with >> 8 as stb_image.h:1198 does;
+    JPEG texels depend on the decoder and may differ by +-1) or wraps an already decoded HxWxC uint8 array.
+    Textures are shared by path as in the reference (src/Material.cu:165-178): a second Texture of a path
+    that is still alive decodes nothing and flattens to the same device texture."""
 
     def __init__(self, path_or_array):
+        global TEXTURE_DECODES
         self.path = ""
-        self.loadSuccess = False
-        self.rgba8: Optional[np.ndarray] = None
+        self._store = _TexelStore()
         if isinstance(path_or_array, np.ndarray):
-            self.rgba8 = expand_to_rgba8(path_or_array)
-            self.loadSuccess = True
+            self._store.rgba8 = expand_to_rgba8(path_or_array)
+            self._store.loadSuccess = True
         else:
             self.path = str(path_or_array)
+            shared = _TEXTURE_MAP.get(self.path)
+            if shared is not None:
+                self._store = shared
+                return
+            _TEXTURE_MAP[self.path] = self._store
+            TEXTURE_DECODES += 1
             try:
                 from PIL import Image
 
@@ -76,10 +98,13 @@ class Texture:
                     arr = np.asarray(im.convert("RGBA" if "transparency" in im.info else "RGB"))
                 else:
                     arr = np.asarray(im.convert("RGB"))
-                self.rgba8 = expand_to_rgba8(arr)
-                self.loadSuccess = True
+                self._store.rgba8 = expand_to_rgba8(arr)
+                self._store.loadSuccess = True
             except Exception:
-                self.loadSuccess = False
+                self._store.loadSuccess = False
+
+    rgba8 = property(lambda self: self._store.rgba8)
+    loadSuccess = property(lambda self: self._store.loadSuccess)
 
     def getWidth(self):
         return 0 if self.rgba8 is None else self.rgba8.shape[1]
@@ -364,10 +389,23 @@ class CustomModel(MeshObject):
     than an exception, textures are looked up next to the asset (or next to its "source"
     directory, :110-112), and a texture that fails to load leaves the material's constant."""
 
+    _MODELS = weakref.WeakValueDictionary()   # path -> _ModelData, alive while any CustomModel of that path is (customModels, :10-45)
+    PARSES = 0                                # files actually parsed (tests)
+
+    class _ModelData:
+        def __init__(self, meshes, materials):
+            self.meshes, self.materials = meshes, materials
+
     def __init__(self, path, position=DEFAULT_POSITION, rotation=DEFAULT_ROTATION, scale=DEFAULT_SCALE):
         from . import assets
 
         self.path = str(path)
+        shared = CustomModel._MODELS.get(self.path)
+        if shared is not None:   # copyHostLLData (:10-19): the same Mesh and Material objects, hence the same device handles
+            self._data = shared
+            super().__init__(list(shared.meshes), list(shared.materials), position, rotation, scale)
+            return
+        CustomModel.PARSES += 1
         meshes, materials = [], []
         try:
             asset = assets.load_asset(self.path)
@@ -386,7 +424,9 @@ class CustomModel(MeshObject):
                 meshes.append((Mesh(fmesh.positions, fmesh.indices, fmesh.uvs, fmesh.normals), int(fmesh.material)))
         except Exception:
             meshes, materials = [], []
-        super().__init__(meshes, materials, position, rotation, scale)
+        self._data = CustomModel._ModelData(meshes, materials)
+        CustomModel._MODELS[self.path] = self._data
+        super().__init__(list(meshes), list(materials), position, rotation, scale)
 
 
 @dataclass
@@ -428,10 +468,11 @@ class Scene:
         def tex(t: Optional[Texture]) -> int:
             if t is None:
                 return -1
-            if id(t) not in tex_id:
-                tex_id[id(t)] = len(fs.textures)
+            key = id(t._store)   # Textures of one path share their texels: one device texture
+            if key not in tex_id:
+                tex_id[key] = len(fs.textures)
                 fs.textures.append(t.rgba8)
-            return tex_id[id(t)]
+            return tex_id[key]
 
         for obj in self.objectMap.values():
             mids, mat_indices = [], []

@@ -40,6 +40,48 @@ def test_cpp_host_renders_the_golden_frame(tmp_path):
     assert im.shape == (64, 64, 4) and tuple(im[0, 0, :3]) == (104, 104, 139)  # sky, top-left after the flip
 
 
+@pytest.mark.gpu
+def test_cpp_frame_counters_and_sharing(tmp_path):
+    """The C++ GPURaytracer advances frameCount / progressiveFrameCount as GPURaytracer.cu:69-73 does (seven frames,
+    progressive on-on-on-off-off-on-on, each compared with the oracle's frame for the expected counters), and
+    Textures / CustomModels of one path share one upload (Material.cu:165-178, CustomModel.cpp:10-24)."""
+    from oracle import oracle_py as orc
+    from raytracer_amd import scenes
+    import test_assets as ta
+    W, H = 72, 48
+    raw, png, model = str(tmp_path / "f.f32"), str(tmp_path / "t.png"), str(tmp_path / "m.fbx")
+    ta.write_fbx(model)
+    p = subprocess.run([EXE, "frames", raw, str(W), str(H), png, model], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    got = np.fromfile(raw, np.float32).reshape(7, H, W, 4)
+    scene, cam, st = scenes.config1(W, H, 2, 3)
+    cam.setPosition((0.6, 0.3, 4.0))
+    flat = scene.flatten()
+    acc = None
+    for k, (fc, pfc) in enumerate([(0, 0), (1, 1), (2, 2), (3, 3), (4, 0), (5, 0), (6, 1)]):
+        st.frameCount, st.progressiveFrameCount = fc, pfc
+        acc, _, _ = orc.render(flat, cam, st, prev=acc)
+        assert np.array_equal(got[k], acc), (k, fc, pfc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 3])
+def test_cpp_one_thread_drives_n_contexts(tmp_path, n):
+    """MultiGPURaytracer (rt_host.hpp): one host thread, n contexts, each rendering its interleaved bands of one frame
+    with one rt_render_bands call; the host composite equals the oracle's frame (8-row bands over 50 rows: ragged)."""
+    from oracle import oracle_py as orc
+    from raytracer_amd import scenes
+    W, H, spp = 70, 50, 3
+    raw = str(tmp_path / "m.f32")
+    p = subprocess.run([EXE, "multi", raw, str(W), str(H), str(spp), str(n)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    scene, cam, st = scenes.config1(W, H, spp, 4)
+    cam.setPosition((0.6, 0.3, 4.0))
+    st.frameCount = 3
+    ref, _, _ = orc.render(scene.flatten(), cam, st)
+    assert np.array_equal(np.fromfile(raw, np.float32).reshape(H, W, 4), ref)
+
+
 def _cpp_asset(path):
     if not os.path.exists(EXE):
         subprocess.check_call(["make", "-s", "-C", os.path.dirname(EXE)])

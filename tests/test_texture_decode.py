@@ -1,0 +1,127 @@
+"""Texture(path) texel bytes (Material.cu:162-206) and the path-keyed sharing of textures and models
+(Material.cu:165-178, 234-252; CustomModel.cpp:10-45) in both host mirrors.  CPU only.
+
+Pinning: oracle/_ref/libstbi_ref.so is the reference's own vendored decoder (src/stb_image.h v2.28) compiled from
+where it lies by `make -C oracle ref`.  When the reference checkout and that build are present (this container),
+every PNG the reference ships is decoded three ways -- stb_image, the Python mirror (PIL) and the C++ mirror's own
+codec -- and the bytes must be identical, 16-bit files included (stb reduces with >> 8, stb_image.h:1198).  JPEG texels
+depend on the decoder (PIL vs stb: <= 3 levels on <= 0.4 % of the bytes of the reference's files): the C++ mirror refuses
+JPEG, the Python mirror decodes it with PIL, and scenes.py binds none of the reference's JPEG maps."""
+import ctypes as C
+import glob
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from raytracer_amd import scene as scn
+from raytracer_amd.scene import CustomModel, Material, Scene, Texture, expand_to_rgba8
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "raytracer_amd", "host", "rt_headless")
+STB = os.path.join(ROOT, "oracle", "_ref", "libstbi_ref.so")
+REF_RES = "/root/reference/res"
+
+
+def cpp_decode(path):
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(EXE)])
+    out = subprocess.run([EXE, "decode", path], capture_output=True, text=True, check=True).stdout.split()
+    return None if out == ["refused"] else tuple(int(v) for v in out)
+
+
+def write_png(path, arr, depth):
+    """Minimal PNG writer for the tests: arr is HxW (gray) or HxWx3 (RGB), uint8 or uint16 by `depth`."""
+    h, w = arr.shape[:2]
+    ch = 1 if arr.ndim == 2 else arr.shape[2]
+    raw = b"".join(b"\x00" + (arr[y].astype(">u2") if depth == 16 else arr[y].astype(np.uint8)).tobytes() for y in range(h))
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    ihdr = struct.pack(">IIBBBBB", w, h, depth, {1: 0, 3: 2}[ch], 0, 0, 0)
+    open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
+def test_sixteen_bit_png_is_reduced_with_shift_8(tmp_path):
+    rng = np.random.default_rng(5)
+    g = rng.integers(0, 65536, (37, 53), dtype=np.uint16)
+    g[0, :4] = (0x00FF, 0x0100, 0x80FF, 0xFFFF)            # >> 8 gives 0, 1, 128, 255; rounding would give 1, 1, 129, 255
+    rgb = rng.integers(0, 65536, (19, 23, 3), dtype=np.uint16)
+    write_png(str(tmp_path / "g16.png"), g, 16)
+    write_png(str(tmp_path / "rgb16.png"), rgb, 16)
+    for name, arr in (("g16.png", g), ("rgb16.png", rgb)):
+        want = (arr >> 8).astype(np.uint8)
+        t = Texture(str(tmp_path / name))
+        assert t.getLoadSuccess() and np.array_equal(t.rgba8, expand_to_rgba8(want))
+        w, h, n, crc = cpp_decode(str(tmp_path / name))
+        assert (w, h, n) == (arr.shape[1], arr.shape[0], 1 if arr.ndim == 2 else 3) and crc == zlib.crc32(want.tobytes())
+    assert tuple(Texture(str(tmp_path / "g16.png")).rgba8[0, :4, 0]) == (0, 1, 128, 255)
+
+
+@pytest.mark.skipif(not (os.path.isdir(REF_RES) and os.path.exists(STB)), reason="needs the reference checkout and `make -C oracle ref`")
+def test_reference_pngs_decode_like_the_references_own_stb_image():
+    L = C.CDLL(STB)
+    L.stbi_load.restype = C.POINTER(C.c_ubyte)
+    L.stbi_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+    L.stbi_image_free.argtypes = [C.c_void_p]
+    files = sorted(glob.glob(REF_RES + "/**/*.png", recursive=True))
+    assert len(files) >= 12
+    sixteen = 0
+    for f in files:
+        w, h, n = C.c_int(), C.c_int(), C.c_int()
+        p = L.stbi_load(f.encode(), C.byref(w), C.byref(h), C.byref(n), 0)     # Material.cu:179: stbi_load(path, ..., 0)
+        assert p, f
+        ref = np.ctypeslib.as_array(p, shape=(h.value, w.value, n.value)).copy()
+        L.stbi_image_free(p)
+        t = Texture(f)
+        assert t.getLoadSuccess() and np.array_equal(t.rgba8, expand_to_rgba8(ref)), f      # Python mirror, after the 4-channel expansion
+        assert cpp_decode(f) == (w.value, h.value, n.value, zlib.crc32(ref.tobytes())), f    # C++ mirror
+        sixteen += struct.unpack(">B", open(f, "rb").read(25)[24:25])[0] == 16
+    assert sixteen >= 2   # Base_Color (RGB16) and Displacement (gray16) are among them
+    # the fixture the GPU box renders with holds the same bytes
+    fx = os.path.join(ROOT, "tests", "golden", "ref_assets.npz")
+    if os.path.exists(fx):
+        z = np.load(fx)
+        for key, rel in (("sword_roughness", "pbrsword/texture/Material.002_Roughness.png"), ("metal_metalness", "metalmaterial/Metal046B_1K-PNG_Metalness.png")):
+            assert np.array_equal(expand_to_rgba8(z[key]), Texture(REF_RES + "/" + rel).rgba8)
+
+
+def test_jpeg_is_refused_by_the_cpp_mirror_and_decoded_by_the_python_one(tmp_path):
+    from PIL import Image
+    img = (np.random.default_rng(2).random((32, 48, 3)) * 255).astype(np.uint8)
+    Image.fromarray(img).save(str(tmp_path / "a.jpg"), quality=90)
+    assert cpp_decode(str(tmp_path / "a.jpg")) is None
+    t = Texture(str(tmp_path / "a.jpg"))
+    assert t.getLoadSuccess() and t.rgba8.shape == (32, 48, 4)
+    m = Material("m")
+    assert m.setAlbedoTexture(str(tmp_path / "a.jpg")) and not m.setAlbedoTexture(str(tmp_path / "missing.png"))
+    assert m.albedoTexture is not None   # a failed load keeps the old texture (setTextureRef, Material.cu:113-130)
+
+
+def test_textures_and_models_are_shared_by_path(tmp_path):
+    img = (np.random.default_rng(3).random((8, 8, 3)) * 255).astype(np.uint8)
+    write_png(str(tmp_path / "t.png"), img, 8)
+    before = scn.TEXTURE_DECODES
+    a, b = Material("a"), Material("b")
+    assert a.setAlbedoTexture(str(tmp_path / "t.png")) and b.setRoughnessTexture(str(tmp_path / "t.png"))
+    assert scn.TEXTURE_DECODES == before + 1 and a.albedoTexture is not b.roughnessTexture
+    assert a.albedoTexture.rgba8 is b.roughnessTexture.rgba8
+    (tmp_path / "q.obj").write_text("v -1 0 -1\nv 1 0 -1\nv 1 0.5 1\nv -1 0 1\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nf 1/1 2/2 3/3 4/4\n")
+    parses = CustomModel.PARSES
+    m1 = CustomModel(str(tmp_path / "q.obj"))
+    m2 = CustomModel(str(tmp_path / "q.obj"), position=(2.0, 0.0, 0.0))
+    assert CustomModel.PARSES == parses + 1 and m1.getLoadSuccess() and m2.getLoadSuccess()
+    assert m1.meshes[0][0] is m2.meshes[0][0]
+    m1.setMaterial(a); m2.setMaterial(b)
+    sc = Scene(); sc.addToScene("m1", m1); sc.addToScene("m2", m2)
+    flat = sc.flatten()
+    assert len(flat.meshes) == 1 and len(flat.textures) == 1 and len(flat.objects) == 2   # one upload each
+    assert flat.objects[1]["model"][12] == np.float32(2.0)
+    del m1, m2, sc, flat
+    import gc
+    gc.collect()
+    CustomModel(str(tmp_path / "q.obj"))
+    assert CustomModel.PARSES == parses + 2   # the last owner gone: parsed again (customModels.erase, CustomModel.cpp:26-45)
