@@ -148,6 +148,20 @@ int rt_framebuffer_write(rt_ctx* ctx, rt_id fb, const float* host_rgba);  /* see
 int rt_framebuffer_enable_ids(rt_ctx* ctx, rt_id fb, int enable);
 int rt_framebuffer_read_ids(rt_ctx* ctx, rt_id fb, uint32_t* host_ids);
 
+/* The display and screenshot side of the reference's window (the "presenter"), without GL:
+ *  - RT_PRESENT_RGBA32F: the frame as the float4 texels RenderWindow uploads to its RGBA32F texture
+ *    (glTexImage2D / glTexSubImage2D, RenderWindow.cpp:172-176, 282-283): host_dst takes width*height*16 bytes and goes
+ *    straight to glTexSubImage2D(GL_TEXTURE_2D, 0, 0, 0, w, h, GL_RGBA, GL_FLOAT, host_dst); row 0 = bottom, as GL wants it;
+ *  - RT_PRESENT_SRGB8: what takeScreenshot reads back (RenderWindow.cpp:389-421: glReadPixels of the GL_FRAMEBUFFER_SRGB
+ *    back buffer, RGBA8): clamp to [0,1], sRGB transfer function, 8 bits, converted on the GPU; host_dst takes
+ *    width*height*4 bytes.  flip_rows != 0 also does the screenshot's vertical flip (row 0 = top, what lodepng is handed).
+ * The 8-bit step is pinned: byte = number of k in 1..255 with value >= T[k-1], T = rt_srgb8_thresholds() (the linear
+ * value whose sRGB encoding is (k - 0.5) / 255, computed in binary64, rounded to binary32), so device and host agree
+ * on every byte.  Synchronises the context stream. */
+enum rt_present_format { RT_PRESENT_RGBA32F = 0, RT_PRESENT_SRGB8 = 1 };
+int rt_present(rt_ctx* ctx, rt_id fb, int format, int flip_rows, void* host_dst);
+const float* rt_srgb8_thresholds(void); /* 255 ascending floats, host memory owned by the library */
+
 /* GPURaytracer::raytrace (GPURaytracer.cu:24-74): one frame of `tile` into fb; asynchronous on
  * the context stream (rt_sync / rt_framebuffer_read wait).  frameCount bookkeeping stays with
  * the caller exactly as Raytracer keeps it (Raytracer.hpp:49-50, GPURaytracer.cu:69-73). */

@@ -61,7 +61,7 @@ EXPORTS = [
     "rt_mesh_create", "rt_mesh_destroy", "rt_texture_create", "rt_texture_destroy", "rt_material_create",
     "rt_material_update", "rt_material_destroy", "rt_object_create", "rt_object_destroy", "rt_scene_commit",
     "rt_camera_set_rays", "rt_framebuffer_create", "rt_framebuffer_wrap", "rt_framebuffer_destroy",
-    "rt_framebuffer_read", "rt_framebuffer_write", "rt_framebuffer_enable_ids", "rt_framebuffer_read_ids",
+    "rt_framebuffer_read", "rt_framebuffer_write", "rt_present", "rt_srgb8_thresholds", "rt_framebuffer_enable_ids", "rt_framebuffer_read_ids",
     "rt_render", "rt_render_bands", "rt_render_noalloc", "rt_trace_rays", "rt_event_record", "rt_event_elapsed_ms", "rt_detmath_eval", "rt_version",
 ]
 

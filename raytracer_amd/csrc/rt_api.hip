@@ -86,6 +86,7 @@ struct rt_ctx {
     uint32_t* dWork = nullptr;      // 8 tile counters (32 words apart) + redo count at word 256
     uint32_t* dRedoList = nullptr; size_t redoCap = 0;
     float bandRel = 2e-4f;          // tie band of the committed scene, see band_rel_of
+    uchar4* dPresent = nullptr; size_t presentCap = 0; float* dSrgb = nullptr;   // rt_present: converted frame, threshold table
     void* scratchPtr = nullptr;     // this device's copy of the static workspace (rt_render_noalloc)
 };
 
@@ -289,9 +290,34 @@ __global__ void detmath_kernel(int op, const float* __restrict__ in, int n, floa
     out[i] = r;
 }
 
+// float4 linear -> RGBA8 sRGB (rt_present): comparisons against the threshold table only, so that the bytes are the host's
+__global__ void present_srgb8_kernel(const float4* __restrict__ fb, int w, int h, int flip, const float* __restrict__ thr,
+                                     uchar4* __restrict__ out)
+{
+    __shared__ float t[256];
+    t[threadIdx.x] = thr[threadIdx.x];
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= (size_t)w * (size_t)h) return;
+    const int y = (int)(i / (size_t)w), x = (int)(i % (size_t)w);
+    const float4 p = fb[(size_t)(flip ? h - 1 - y : y) * (size_t)w + (size_t)x];
+    auto enc = [&](float v) -> unsigned char { // number of thresholds <= v; NaN counts as 0
+        int lo = 0, hi = 255;                  // invariant: t[lo - 1] <= v < t[hi] (t[255] = +inf)
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (v >= t[mid]) lo = mid + 1; else hi = mid; }
+        return (unsigned char)lo;
+    };
+    const float a = p.w != p.w ? 0.0f : (p.w < 0.0f ? 0.0f : (p.w > 1.0f ? 1.0f : p.w));
+    out[i] = make_uchar4(enc(p.x), enc(p.y), enc(p.z), (unsigned char)(a * 255.0f + 0.5f));
+}
+
 } // namespace
 
 namespace rt {
+void launch_present_srgb8(const float4* fb, int w, int h, bool flip, const float* thr, uchar4* out, hipStream_t stream)
+{
+    const size_t n = (size_t)w * (size_t)h;
+    hipLaunchKernelGGL(present_srgb8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, fb, w, h, flip ? 1 : 0, thr, out);
+}
 void launch_detmath(int op, const float* in, int n, float* out, hipStream_t stream)
 {
     hipLaunchKernelGGL(detmath_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, op, in, n, out);
@@ -363,7 +389,7 @@ int rt_ctx_destroy(rt_ctx* c)
     for (auto& t : c->textures) if (t.live) hipFree(t.data);
     for (auto& f : c->fbs) if (f.live) { if (f.owned) hipFree(f.data); hipFree(f.ids); }
     rt::free_scene(c->built);
-    hipFree(c->dObjects); hipFree(c->dMaterials); hipFree(c->dRays); hipFree(c->dCounters); hipFree(c->dWork); hipFree(c->dRedoList);
+    hipFree(c->dObjects); hipFree(c->dMaterials); hipFree(c->dRays); hipFree(c->dPresent); hipFree(c->dSrgb); hipFree(c->dCounters); hipFree(c->dWork); hipFree(c->dRedoList);
     free_wf(c);
     if (c->hCounters) hipHostFree(c->hCounters);
     if (c->evBegin) hipEventDestroy(c->evBegin);
@@ -741,6 +767,58 @@ int rt_framebuffer_write(rt_ctx* c, rt_id id, const float* host)
     if (!valid(c->fbs, id) || !host) return fail(c, RT_ERR_INVALID, "invalid framebuffer handle or null host pointer");
     const FbRec& f = c->fbs[id];
     RT_CHECK(c, hipMemcpyAsync(f.data, host, sizeof(float4) * (size_t)f.w * (size_t)f.h, hipMemcpyHostToDevice, c->stream));
+    RT_CHECK(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+const float* rt_srgb8_thresholds(void)
+{
+    static float table[255];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (int k = 1; k <= 255; k++) { // inverse sRGB transfer function at (k - 0.5) / 255, IEC 61966-2-1
+            const double e = ((double)k - 0.5) / 255.0;
+            const double lin = e <= 0.04045 ? e / 12.92 : std::pow((e + 0.055) / 1.055, 2.4);
+            table[k - 1] = (float)lin;
+        }
+    });
+    return table;
+}
+
+int rt_present(rt_ctx* c, rt_id id, int format, int flipRows, void* host)
+{
+    RT_BIND(c);
+    if (!valid(c->fbs, id) || !host) return fail(c, RT_ERR_INVALID, "invalid framebuffer handle or null host pointer");
+    const FbRec& f = c->fbs[id];
+    const size_t n = (size_t)f.w * (size_t)f.h;
+    if (format == RT_PRESENT_RGBA32F) {
+        if (!flipRows) {
+            RT_CHECK(c, hipMemcpyAsync(host, f.data, sizeof(float4) * n, hipMemcpyDeviceToHost, c->stream));
+        } else { // row by row, last source row first
+            for (int y = 0; y < f.h; y++)
+                RT_CHECK(c, hipMemcpyAsync((char*)host + sizeof(float4) * (size_t)f.w * (size_t)y, f.data + (size_t)(f.h - 1 - y) * f.w,
+                                           sizeof(float4) * (size_t)f.w, hipMemcpyDeviceToHost, c->stream));
+        }
+        RT_CHECK(c, hipStreamSynchronize(c->stream));
+        return RT_OK;
+    }
+    if (format != RT_PRESENT_SRGB8) return fail(c, RT_ERR_INVALID, "rt_present: unknown format");
+    if (n > c->presentCap) { // staging for the converted frame; grows with the largest frame presented
+        RT_CHECK(c, hipStreamSynchronize(c->stream));
+        hipFree(c->dPresent); c->dPresent = nullptr; c->presentCap = 0;
+        RT_CHECK(c, hipMalloc((void**)&c->dPresent, 4 * n));
+        c->presentCap = n;
+    }
+    if (!c->dSrgb) {
+        RT_CHECK(c, hipMalloc((void**)&c->dSrgb, sizeof(float) * 256));
+        float t[256];
+        memcpy(t, rt_srgb8_thresholds(), sizeof(float) * 255);
+        t[255] = INFINITY;
+        RT_CHECK(c, hipMemcpy(c->dSrgb, t, sizeof(t), hipMemcpyHostToDevice));
+    }
+    rt::launch_present_srgb8(f.data, f.w, f.h, flipRows != 0, c->dSrgb, c->dPresent, c->stream);
+    RT_CHECK(c, hipGetLastError());
+    RT_CHECK(c, hipMemcpyAsync(host, c->dPresent, 4 * n, hipMemcpyDeviceToHost, c->stream));
     RT_CHECK(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }

@@ -57,6 +57,7 @@ int wf_tile_rows(const RenderArgs& a);
 void launch_render_wf(const RenderArgs& a, const WfLanes& L, int numCUs, hipStream_t mainStream);
 void launch_trace_rays(const SceneView& s, const float4* rays, int n, uint4* out, unsigned long long* counters, int mode,
                        hipStream_t stream);
+void launch_present_srgb8(const float4* fb, int w, int h, bool flip, const float* thr, uchar4* out, hipStream_t stream);
 void launch_detmath(int op, const float* in, int n, float* out, hipStream_t stream);
 
 } // namespace rt

@@ -568,20 +568,12 @@ public:
     int width() const { return w_; }
     int height() const { return h_; }
     std::vector<float> read() const { std::vector<float> v((size_t)w_ * h_ * 4); dev_.check(rt_framebuffer_read(dev_.ctx(), id_, v.data())); return v; }
-    // takeScreenshot: the reference reads the sRGB-encoded back buffer and flips it; row 0 of the
-    // render buffer is the bottom of the picture
-    bool savePNG(const std::string& path) const
-    {
-        const std::vector<float> f = read();
-        std::vector<unsigned char> px((size_t)w_ * h_ * 4);
-        for (int y = 0; y < h_; y++) for (int x = 0; x < w_; x++) for (int c = 0; c < 4; c++) {
-            float v = f[((size_t)(h_ - 1 - y) * w_ + x) * 4 + c];
-            v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-            if (c < 3) v = v <= 0.0031308f ? 12.92f * v : 1.055f * std::pow(v, 1.0f / 2.4f) - 0.055f;
-            px[((size_t)y * w_ + x) * 4 + c] = (unsigned char)(v * 255.0f + 0.5f);
-        }
-        return png::encode(path, px.data(), (unsigned)w_, (unsigned)h_);
-    }
+    // the texels RenderWindow uploads to its RGBA32F texture (RenderWindow.cpp:172-176, 282-283): pass data() to glTexSubImage2D
+    std::vector<float> present() const { std::vector<float> v((size_t)w_ * h_ * 4); dev_.check(rt_present(dev_.ctx(), id_, RT_PRESENT_RGBA32F, 0, v.data())); return v; }
+    // takeScreenshot (RenderWindow.cpp:389-421): the reference reads the sRGB-encoded back buffer and flips it; row 0 of
+    // the render buffer is the bottom of the picture.  Converted and flipped on the GPU (rt_present).
+    std::vector<unsigned char> screenshot() const { std::vector<unsigned char> px((size_t)w_ * h_ * 4); dev_.check(rt_present(dev_.ctx(), id_, RT_PRESENT_SRGB8, 1, px.data())); return px; }
+    bool savePNG(const std::string& path) const { const std::vector<unsigned char> px = screenshot(); return png::encode(path, px.data(), (unsigned)w_, (unsigned)h_); }
 private:
     Device& dev_;
     int w_, h_;

@@ -226,3 +226,46 @@ def test_render_bands_compose_the_frame(ctx, mode):
     with pytest.raises(capi.RtError, match="multiple of 8"):
         ctx.render(cam, st, fb, None, bands=(12, 0, 2))
     ctx.framebuffer_destroy(fb); ctx.framebuffer_destroy(fb2)
+
+
+def test_present_and_screenshot(ctx, tmp_path):
+    """rt_present: the RGBA32F texels the reference's window uploads for display (RenderWindow.cpp:172-176, 282-283) and the
+    flipped sRGB8 screenshot (RenderWindow.cpp:389-421), converted on the GPU, byte for byte the host restatement --
+    on a rendered frame (its sky is the reference's one known answer, sRGB8 (104,104,139)) and on adversarial values."""
+    from raytracer_amd import present
+    scene, cam, st = scenes.config1(96, 64, 2, 3)
+    ctx.set_option(capi.OPT_TRAVERSAL, 0)
+    ctx.upload_scene(scene.flatten())
+    ctx.set_camera_rays(cam.preTransformRays)
+    fb = ctx.framebuffer(96, 64)
+    ctx.render(cam, st, fb)
+    lin = ctx.read(fb, 96, 64)
+    assert np.array_equal(present.present_rgba32f(ctx, fb, 96, 64), lin)
+    assert np.array_equal(present.present_rgba32f(ctx, fb, 96, 64, flip=True), lin[::-1])
+    table = present.thresholds(ctx.L)
+    assert np.all(np.diff(table) > 0) and np.abs(table.view(np.int32) - present.thresholds_python().view(np.int32)).max() <= 1
+    shot = present.screenshot(ctx, fb, 96, 64)
+    assert np.array_equal(shot, present.to_srgb8(lin, table, flip=True))
+    assert tuple(shot[0, 0]) == (104, 104, 139, 255)                       # top-left: sky (README screenshots of the reference)
+    assert np.array_equal(present.screenshot(ctx, fb, 96, 64, flip=False), present.to_srgb8(lin, table, flip=False))
+    present.save_png(str(tmp_path / "s.png"), shot)
+    from PIL import Image
+    assert np.array_equal(np.asarray(Image.open(str(tmp_path / "s.png"))), shot)
+    # every threshold, its neighbours, and values outside [0, 1] / non-finite
+    t = np.concatenate([table, np.nextafter(table, np.float32(-1)), np.nextafter(table, np.float32(2)),
+                        np.array([0.0, -0.0, 1.0, -1.0, 2.0, np.inf, -np.inf, np.nan, 1e-30, 0.5], np.float32)]).astype(np.float32)
+    img = np.zeros((64, 96, 4), np.float32)
+    img.reshape(-1, 4)[:t.size, 0] = t
+    img.reshape(-1, 4)[:t.size, 1] = t[::-1]
+    img.reshape(-1, 4)[:t.size, 3] = np.clip(t, 0, 1)
+    ctx.write(fb, img)
+    got = present.screenshot(ctx, fb, 96, 64)
+    assert np.array_equal(got, present.to_srgb8(img, table, flip=True))
+    # against the textbook formula on random values (away from the thresholds the two agree on every byte)
+    rnd = np.random.default_rng(9).random((64, 96, 4)).astype(np.float32)
+    ctx.write(fb, rnd)
+    got = present.screenshot(ctx, fb, 96, 64, flip=False)
+    x = rnd[..., :3].astype(np.float64)
+    enc = np.where(x <= 0.0031308, 12.92 * x, 1.055 * x ** (1 / 2.4) - 0.055)
+    assert np.array_equal(got[..., :3], np.floor(enc * 255.0 + 0.5).astype(np.uint8))
+    ctx.framebuffer_destroy(fb)
