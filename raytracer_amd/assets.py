@@ -326,7 +326,15 @@ _FBX_ARRAY = {b"f": "<f4", b"d": "<f8", b"l": "<i8", b"i": "<i4", b"b": "u1"}
 _FBX_SCALAR = {b"Y": "<h", b"C": "<?", b"I": "<i", b"F": "<f", b"D": "<d", b"L": "<q"}
 
 
-def _fbx_read_node(d, pos, wide):
+_FBX_MAX_DEPTH = 64
+
+
+def _fbx_read_node(d, pos, wide, depth=0):
+    """One node record.  A malformed or truncated file raises (struct.error / ValueError), which CustomModel turns into
+    getLoadSuccess() == False: reads are bounds-checked by struct, a compressed array may inflate to n * itemsize bytes
+    and no further, a record must end inside the file and after its start, nesting is limited."""
+    if depth > _FBX_MAX_DEPTH:
+        raise ValueError("FBX: nesting too deep")
     if wide:
         end, nprop, _plen = struct.unpack_from("<QQQ", d, pos)
         pos += 24
@@ -337,6 +345,8 @@ def _fbx_read_node(d, pos, wide):
     pos += 1
     if end == 0:
         return None, pos
+    if end > len(d) or end < pos + nlen:
+        raise ValueError("FBX: record end outside the file")
     name = d[pos:pos + nlen].decode("ascii", "replace")
     pos += nlen
     props = []
@@ -350,10 +360,17 @@ def _fbx_read_node(d, pos, wide):
         elif t in _FBX_ARRAY:
             n, enc, clen = struct.unpack_from("<III", d, pos)
             pos += 12
+            if pos + clen > len(d):
+                raise ValueError("FBX: array past the end of the file")
             raw = d[pos:pos + clen]
             pos += clen
+            want = n * np.dtype(_FBX_ARRAY[t]).itemsize
             if enc == 1:
-                raw = zlib.decompress(raw)
+                if want > clen * 1100 + 64:   # deflate expands at most ~1032-fold
+                    raise ValueError("FBX: array larger than its compressed bytes can hold")
+                raw = zlib.decompressobj().decompress(raw, want + 1)
+            if len(raw) < want:
+                raise ValueError("FBX: array shorter than declared")
             props.append(np.frombuffer(raw, dtype=_FBX_ARRAY[t], count=n))
         elif t in (b"S", b"R"):
             n = struct.unpack_from("<I", d, pos)[0]
@@ -364,7 +381,7 @@ def _fbx_read_node(d, pos, wide):
             raise ValueError(f"FBX: unknown property type {t!r}")
     children = []
     while pos < end:
-        c, pos = _fbx_read_node(d, pos, wide)
+        c, pos = _fbx_read_node(d, pos, wide, depth + 1)
         if c is None:
             break
         children.append(c)

@@ -361,21 +361,29 @@ struct FbxNode {
 };
 template <class T> inline T rd(const std::string& d, size_t pos) { T v; memcpy(&v, d.data() + pos, sizeof(T)); return v; }
 
-inline bool fbxRead(const std::string& d, size_t& pos, bool wide, std::unique_ptr<FbxNode>& out)
+// Every read is checked against the buffer, array sizes against what the bytes present can hold (a deflate stream expands
+// at most ~1032-fold), the record's end against its start and the file, and the nesting against a fixed depth: a malformed
+// or truncated file gives false, never a read past the buffer, an allocation the file cannot back, or unbounded recursion.
+constexpr int kFbxMaxDepth = 64;
+inline bool fbxRead(const std::string& d, size_t& pos, bool wide, std::unique_ptr<FbxNode>& out, int depth = 0)
 {
     const size_t head = wide ? 24 : 12;
-    if (pos + head + 1 > d.size()) return false;
+    if (depth > kFbxMaxDepth || pos + head + 1 > d.size()) return false;
     uint64_t end, nprop;
     if (wide) { end = rd<uint64_t>(d, pos); nprop = rd<uint64_t>(d, pos + 8); } else { end = rd<uint32_t>(d, pos); nprop = rd<uint32_t>(d, pos + 4); }
     pos += head;
     const unsigned nlen = (unsigned char)d[pos++];
     if (end == 0) { out.reset(); return true; }
-    if (end > d.size() || pos + nlen > d.size()) return false;
+    if (end > d.size() || end < pos || pos + nlen > end) return false;
     out = std::make_unique<FbxNode>();
     out->name = d.substr(pos, nlen); pos += nlen;
     for (uint64_t k = 0; k < nprop; k++) {
         if (pos >= d.size()) return false;
         FbxProp p; p.type = d[pos++];
+        const size_t left = d.size() - pos;
+        const size_t need = p.type == 'Y' ? 2 : p.type == 'C' ? 1 : (p.type == 'I' || p.type == 'F' || p.type == 'S' || p.type == 'R') ? 4
+                          : (p.type == 'L' || p.type == 'D') ? 8 : 12;
+        if (left < need) return false;
         switch (p.type) {
         case 'Y': p.i = rd<int16_t>(d, pos); pos += 2; break;
         case 'C': p.i = d[pos] != 0; pos += 1; break;
@@ -389,6 +397,7 @@ inline bool fbxRead(const std::string& d, size_t& pos, bool wide, std::unique_pt
             pos += 12;
             if (pos + clen > d.size()) return false;
             const size_t esz = p.type == 'f' || p.type == 'i' ? 4 : (p.type == 'b' ? 1 : 8);
+            if ((uint64_t)n * esz > (enc == 1 ? (uint64_t)clen * 1100u + 64u : (uint64_t)clen)) return false;
             std::vector<unsigned char> raw((size_t)n * esz);
             if (enc == 1) { uLongf rl = (uLongf)raw.size(); if (uncompress(raw.data(), &rl, (const Bytef*)d.data() + pos, clen) != Z_OK || rl != raw.size()) return false; }
             else { if (clen < raw.size()) return false; memcpy(raw.data(), d.data() + pos, raw.size()); }
@@ -408,7 +417,7 @@ inline bool fbxRead(const std::string& d, size_t& pos, bool wide, std::unique_pt
     }
     while (pos < end) {
         std::unique_ptr<FbxNode> c;
-        if (!fbxRead(d, pos, wide, c)) return false;
+        if (!fbxRead(d, pos, wide, c, depth + 1)) return false;
         if (!c) break;
         out->kids.push_back(std::move(c));
     }

@@ -194,3 +194,40 @@ def test_reference_model_files():
     assert fbx.texture_directory() == REF + "/pbrsword"
     for m in dae.meshes + fbx.meshes:
         assert np.isfinite(m.positions).all() and m.indices.min() >= 0 and m.indices.max() < m.positions.shape[0]
+
+
+def test_malformed_fbx_files_fail_cleanly(tmp_path):
+    """Truncated and corrupted binary FBX files give getLoadSuccess() == False in both mirrors: no read past the buffer,
+    no allocation the file cannot back, no unbounded recursion (the reference would hand them to assimp)."""
+    import struct
+    import subprocess
+    from raytracer_amd.scene import CustomModel
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracer_amd", "host", "rt_headless")
+    good = str(tmp_path / "good.fbx")
+    write_fbx(good)
+    data = open(good, "rb").read()
+    assert CustomModel(good).getLoadSuccess()
+    cases = {}
+    for cut in (28, 40, 100, len(data) // 2, len(data) - 30):
+        cases[f"cut{cut}"] = data[:cut]
+    bomb = bytearray(data)
+    k = data.find(b"d", 60)                       # some array property: declare 2^31 elements
+    i = data.find(b"Vertices")
+    j = i + len(b"Vertices")
+    assert data[j:j + 1] == b"d"
+    bomb[j + 1:j + 5] = struct.pack("<I", 0x7FFFFFFF)
+    cases["bomb"] = bytes(bomb)
+    end_bad = bytearray(data)
+    end_bad[27:31] = struct.pack("<I", 0xFFFFFF00)  # first record ends far outside the file
+    cases["end"] = bytes(end_bad)
+    nest = bytearray(data[:27])
+    for _ in range(200):                          # 200 nested empty records, each "ending" at the end of the file
+        nest += struct.pack("<III", 27 + 200 * 14 + 13, 0, 0) + b"\\x01N"
+    nest += b"\\x00" * 13
+    cases["nest"] = bytes(nest)
+    for name, blob in cases.items():
+        p = str(tmp_path / (name + ".fbx"))
+        open(p, "wb").write(blob)
+        assert not CustomModel(p).getLoadSuccess(), name
+        r = subprocess.run([exe, "asset", p], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 3 and "load failed" in r.stdout, (name, r.returncode, r.stdout, r.stderr)
