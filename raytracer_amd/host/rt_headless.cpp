@@ -144,6 +144,35 @@ int main(int argc, char** argv)
         } catch (const std::exception& e) { fprintf(stderr, "error: %s\n", e.what()); return 2; }
         return 0;
     }
+    if (argc >= 5 && std::string(argv[1]) == "legacy") {
+        // the reference's legacy CPURaytracer (its "Use GPU" toggle off) on a small textured scene: cube with an albedo map,
+        // rotated and scaled sphere, emissive cube; rendered on the host, written as float4
+        try {
+            const int W = atoi(argv[3]), H = atoi(argv[4]);
+            Device dev(0);
+            std::vector<unsigned char> tex(16 * 16 * 3);
+            for (int i = 0; i < 16 * 16; i++) { tex[i * 3] = (unsigned char)(i * 7 + 30); tex[i * 3 + 1] = (unsigned char)(255 - i); tex[i * 3 + 2] = (unsigned char)((i * 13) & 255); }
+            auto a = std::make_shared<Material>(dev, "a", vec4{ 0.8f, 0.3f, 0.2f, 1.0f }, 0.4f, 0.1f);
+            a->setAlbedoTexture(std::make_shared<Texture>(dev, tex.data(), 16, 16, 3));
+            auto b = std::make_shared<Material>(dev, "b", vec4{ 0.2f, 0.6f, 0.9f, 1.0f }, 0.7f, 0.0f, vec3{ 0.05f, 0.1f, 0.02f }, 1.0f);
+            auto e = std::make_shared<Material>(dev, "e", vec4{ 0.9f, 0.9f, 0.9f, 1.0f }, 0.5f, 0.0f, vec3{ 1.0f, 0.8f, 0.5f }, 2.0f);
+            Scene scene(dev);
+            auto cube = std::make_shared<Cube>(dev); cube->setPosition({ -0.7f, 0.0f, 0.0f }); cube->setRotation({ 0.0f, 0.1f, 0.0f, 0.995f }); cube->setScale({ 1.3f, 1.6f, 1.1f }); cube->setMaterial(a);
+            auto sphere = std::make_shared<Sphere>(dev, vec3{ 0.9f, 0.1f, 0.3f }, quat{ 0.1f, 0.2f, 0.0f, 0.97f }, vec3{ 1.4f, 1.0f, 1.2f }); sphere->setMaterial(b);
+            auto lamp = std::make_shared<Cube>(dev); lamp->setPosition({ 0.2f, 1.6f, 0.5f }); lamp->setScale({ 3.0f, 0.2f, 3.0f }); lamp->setMaterial(e);
+            scene.addToScene("cube", cube); scene.addToScene("sphere", sphere); scene.addToScene("lamp", lamp);
+            Camera cam(dev, vec3{ 0.1f, 0.4f, 5.0f }, quat{ -0.05f, 0.02f, 0.0f, 0.998f }, 45.0f, 1.2f);
+            cam.setWidth(W); cam.setHeight(H);
+            CPURaytracer rt;
+            rt.setBounceCount(3); rt.setAOIntensity(0.05f);
+            const std::vector<float> px = rt.raytrace(scene, cam);
+            FILE* f = fopen(argv[2], "wb");
+            if (!f || fwrite(px.data(), 4, px.size(), f) != px.size()) return 6;
+            fclose(f);
+            printf("ok legacy\n");
+        } catch (const std::exception& ex) { fprintf(stderr, "error: %s\n", ex.what()); return 2; }
+        return 0;
+    }
     if (argc >= 7 && std::string(argv[1]) == "multi") {
         // one thread, N contexts (all on GPU 0 here): the interleaved bands of one frame, composited on the host
         try {

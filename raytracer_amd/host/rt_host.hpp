@@ -221,6 +221,17 @@ public:
     bool getLoadSuccess() const { return store_->loadSuccess; }
     std::string getPath() const { return path_; }
     rt_id id() const { return store_->id; }
+    // Texture::sampleTexture (Material.cu:253-266), the legacy CPU renderer's nearest-texel fetch: (0,0,0,0) outside [0,1]^2,
+    // texel (int)(x * width), (int)(y * height) of the 4-channel float copy (value = byte / 255.0f, :199-206).  The
+    // reference reads past the row / the array at x == 1 or y == 1; those reads give 0 here.
+    vec4 sampleTexture(float x, float y) const
+    {
+        if (x < 0.0f || x > 1.0f || y < 0.0f || y > 1.0f) return {};
+        const int ix = (int)(x * store_->width), iy = (int)(y * store_->height);
+        const size_t index = ((size_t)iy * store_->width + ix) * 4;
+        auto at = [&](size_t k) { return k < store_->rgba.size() ? (float)store_->rgba[k] / 255.0f : 0.0f; };
+        return { at(index), at(index + 1), at(index + 2), at(index + 3) };
+    }
 private:
     struct Store { // the device texture the Textures of one path share; freed with the last of them (ref count, Material.cu:234-252)
         explicit Store(Device& d) : dev(d) {}
@@ -234,8 +245,10 @@ private:
             for (size_t i = 0; i < np; i++) { rgba[i * 4] = at(i * n); rgba[i * 4 + 1] = at(i * n + 1); rgba[i * 4 + 2] = at(i * n + 2); rgba[i * 4 + 3] = n == 4 ? at(i * n + 3) : 255; }
             loadSuccess = rt_texture_create(dev.ctx(), rgba.data(), width, height, &id) == RT_OK;
             dev.textureUploads++;
+            this->rgba = std::move(rgba); // host copy, as the reference keeps one (Texture::data) for its CPU renderer
         }
         Device& dev;
+        std::vector<unsigned char> rgba;
         int width = 0, height = 0;
         bool loadSuccess = false;
         rt_id id = -1;
@@ -276,6 +289,14 @@ public:
         dev_.check(id_ < 0 ? rt_material_create(dev_.ctx(), &d, &id_) : rt_material_update(dev_.ctx(), id_, &d));
     }
     rt_id id() { if (id_ < 0) sendToGPU(); return id_; }
+    // host-side getters of the legacy CPU renderer (Material.cu:58-110): constant, or nearest texel of the bound map
+    vec3 getNormal(float x, float y) const { if (!normalTexture) return { 0.0f, 0.0f, 1.0f }; const vec4 t = normalTexture->sampleTexture(x, y); return { t.x, t.y, t.z }; }
+    vec4 getAlbedo(float x, float y) const { return albedoTexture ? albedoTexture->sampleTexture(x, y) : simpleAlbedo; }
+    float getRoughness(float x, float y) const { return roughnessTexture ? roughnessTexture->sampleTexture(x, y).x : simpleRoughness; }
+    float getMetal(float x, float y) const { return metalTexture ? metalTexture->sampleTexture(x, y).x : simpleMetal; }
+    vec3 getAmbientOcclusion(float x, float y) const { if (!ambientOcclusionTexture) return { 1.0f, 1.0f, 1.0f }; const vec4 t = ambientOcclusionTexture->sampleTexture(x, y); return { t.x, t.y, t.z }; }
+    vec3 getEmissionColor(float x, float y) const { if (!emissionTexture) return simpleEmissionColor; const vec4 t = emissionTexture->sampleTexture(x, y); return { t.x, t.y, t.z }; }
+    float getEmissionStrength() const { return emissionStrength; }
 private:
     bool setRef(std::shared_ptr<Texture>& slot, const char* path)
     {
@@ -342,6 +363,8 @@ public:
     bool getLoadSuccess() const { return loadSuccess; }
     const std::vector<std::pair<std::shared_ptr<Mesh>, int>>& getMeshes() const { return meshes; }
     const std::vector<std::shared_ptr<Material>>& getMaterials() const { return materials; }
+    Mesh* getMesh() const { return meshes[0].first.get(); }                          // DisplayObject.hpp:49: the first mesh only
+    Material* getMaterial() const { return materials[meshes[0].second].get(); }      // :50
     void sendToGPU()
     {
         std::vector<rt_id> mi, ma; std::vector<int32_t> mx;
@@ -550,6 +573,17 @@ public:
     void setHeight(int h) { height = h; }
     void setWidth(int w) { width = w; }
     const std::vector<float>& rays() const { return preTransformRays; }
+    int getPixelCount() const { return width * height; }
+    // Camera::getRayDirection (Camera.hpp:105): Rotation * preTransformRays[y * width + x], glm's quat * vec3
+    // (detail/type_quat.inl:343-350): v + ((cross(q.xyz, v) * q.w) + cross(q.xyz, cross(q.xyz, v))) * 2
+    vec3 getRayDirection(int x, int y) const
+    {
+        const float* r = &preTransformRays[((size_t)y * width + x) * 4];
+        const vec3 v{ r[0], r[1], r[2] }, q{ Rotation.x, Rotation.y, Rotation.z };
+        auto cross = [](vec3 a, vec3 b) { return vec3{ a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y }; };
+        const vec3 uv = cross(q, v), uuv = cross(q, uv);
+        return { v.x + ((uv.x * Rotation.w) + uuv.x) * 2.0f, v.y + ((uv.y * Rotation.w) + uuv.y) * 2.0f, v.z + ((uv.z * Rotation.w) + uuv.z) * 2.0f };
+    }
 private:
     Device& dev_;
     vec3 Position; quat Rotation;
@@ -631,6 +665,180 @@ public:
     }
 private:
     Device& dev_;
+};
+
+// ---------------------------------------------------------------- CPURaytracer (processor/CPU/CPURaytracer.hpp / .cpp), SURVEY 8f-4
+// The reference's legacy renderer behind its "Use GPU" toggle: single-threaded, diffuse only (no sky, no BRDF), nearest
+// texel, ONE random seed walked through the whole frame in pixel order (CPURaytracer.hpp:44), only the first mesh of an
+// object (DisplayObject.hpp:49), an object pre-cull against the box spanned by the model-transformed min and max corners
+// (:52-56; not an axis-aligned bound once the object is rotated -- reproduced).  Host code: nothing here touches the GPU.
+// The transcendentals are the C library's float functions (logf, cosf, expf), as the reference's <cmath> calls resolve; the
+// reference ran MSVC's, so the last bit of a bounce direction is not pinned by anything (parity unpinned).
+class CPURaytracer : public Raytracer {
+public:
+    // CPURaytracer::raytrace (:6-40): W*H*4 floats, alpha 1
+    std::vector<float> raytrace(Scene& scene, Camera& camera)
+    {
+        camera.update();
+        auto& objects = scene.getObjects();
+        std::vector<float> output((size_t)camera.getPixelCount() * 4, 1.0f);
+        const vec3 origin = camera.getPosition();
+        const float exposure = camera.getExposure();
+        for (int y = 0; y < camera.getHeight(); y++)
+            for (int x = 0; x < camera.getWidth(); x++) {
+                CRay ray{};
+                ray.origin = origin; ray.direction = camera.getRayDirection(x, y); ray.bounceCount = bounceCount;
+                const vec3 c = singleTrace(ray, objects);
+                const size_t i = (size_t)y * camera.getWidth() + x;
+                output[4 * i] = 1.0f - std::exp(-c.x * exposure);   // glm::exp(vec3) = std::exp per float component
+                output[4 * i + 1] = 1.0f - std::exp(-c.y * exposure);
+                output[4 * i + 2] = 1.0f - std::exp(-c.z * exposure);
+            }
+        return output;
+    }
+    void setSeed(unsigned s) { randomSeed = s; }
+private:
+    struct CHit { vec3 hitPosition; float distance; float u, v; Material* material; vec3 t, b, n; vec3 normal; };
+    struct CRay { vec3 origin, direction; int bounceCount; bool didHit; CHit hitInfo; };
+    using Objects = std::vector<std::pair<std::string, std::shared_ptr<DisplayObject>>>;
+    static vec3 mulPoint(const mat4& m, vec3 v, float w) // glm mat4 * vec4 (detail/type_mat4x4.inl): the mul/add order of its four column products
+    {
+        const float m0x = m.c[0][0] * v.x, m0y = m.c[0][1] * v.x, m0z = m.c[0][2] * v.x;
+        const float m1x = m.c[1][0] * v.y, m1y = m.c[1][1] * v.y, m1z = m.c[1][2] * v.y;
+        const float m2x = m.c[2][0] * v.z, m2y = m.c[2][1] * v.z, m2z = m.c[2][2] * v.z;
+        const float m3x = m.c[3][0] * w, m3y = m.c[3][1] * w, m3z = m.c[3][2] * w;
+        return { (m0x + m1x) + (m2x + m3x), (m0y + m1y) + (m2y + m3y), (m0z + m1z) + (m2z + m3z) };
+    }
+    static vec3 normalize3(vec3 v) { const float s = 1.0f / std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z); return { v.x * s, v.y * s, v.z * s }; } // v * inversesqrt(dot(v, v))
+    static vec3 cross3(vec3 a, vec3 b) { return { a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y }; }
+    static float comp(vec3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
+
+    vec3 singleTrace(CRay& ray, const Objects& objects) // :42-84
+    {
+        vec3 incoming{ 0, 0, 0 }, rayColor{ 1, 1, 1 };
+        for (int i = 0; i < bounceCount; i++) {
+            for (auto& op : objects) {
+                DisplayObject* object = op.second.get();
+                const mat4 model = object->getModelMatrix();
+                const float* mn = object->getMesh()->getMinBound(); const float* mx = object->getMesh()->getMaxBound();
+                if (!intersectsBoundingBox(ray, mulPoint(model, { mn[0], mn[1], mn[2] }, 1.0f), mulPoint(model, { mx[0], mx[1], mx[2] }, 1.0f))) continue;
+                getIntersectionPoint(ray, object, model);
+            }
+            if (!ray.didHit) break;
+            Material* m = ray.hitInfo.material;
+            const float u = ray.hitInfo.u, v = ray.hitInfo.v;
+            const vec3 nl = m->getNormal(u, v); // setMaterialData (:199-207): normal = tbn * map normal
+            ray.hitInfo.normal = { ray.hitInfo.t.x * nl.x + ray.hitInfo.b.x * nl.y + ray.hitInfo.n.x * nl.z,
+                                   ray.hitInfo.t.y * nl.x + ray.hitInfo.b.y * nl.y + ray.hitInfo.n.y * nl.z,
+                                   ray.hitInfo.t.z * nl.x + ray.hitInfo.b.z * nl.y + ray.hitInfo.n.z * nl.z };
+            const vec4 al = m->getAlbedo(u, v);
+            if (i == 0) { const vec3 ao = m->getAmbientOcclusion(u, v); incoming.x += ao.x * al.x * aoIntensity; incoming.y += ao.y * al.y * aoIntensity; incoming.z += ao.z * al.z * aoIntensity; }
+            const vec3 em = m->getEmissionColor(u, v); const float es = m->getEmissionStrength();
+            incoming.x += rayColor.x * em.x * es; incoming.y += rayColor.y * em.y * es; incoming.z += rayColor.z * em.z * es;
+            rayColor.x *= al.x; rayColor.y *= al.y; rayColor.z *= al.z;
+            if (i < ray.bounceCount - 1) {
+                ray.origin = ray.hitInfo.hitPosition;
+                ray.direction = randomUnitVectorInHemisphere(randomSeed, ray.hitInfo.normal);
+                ray.didHit = false;
+            }
+        }
+        return incoming;
+    }
+    bool intersectsBoundingBox(const CRay& ray, vec3 minBound, vec3 maxBound) const // :86-105
+    {
+        float tmin = 0.0f, tmax = ray.didHit ? ray.hitInfo.distance : INFINITY;
+        for (int d = 0; d < 3; d++) {
+            const float dir = comp(ray.direction, d), inv = 1.0f / dir, o = comp(ray.origin, d);
+            const bool sign = std::signbit(dir);
+            const float bmin = sign ? comp(maxBound, d) : comp(minBound, d), bmax = sign ? comp(minBound, d) : comp(maxBound, d);
+            const float dmin = (bmin - o) * inv, dmax = (bmax - o) * inv;
+            tmin = dmin > tmin ? dmin : tmin;   // the class's own max / min (CPURaytracer.hpp:63-64)
+            tmax = dmax < tmax ? dmax : tmax;
+        }
+        return tmin < tmax;
+    }
+    void getIntersectionPoint(CRay& ray, DisplayObject* object, const mat4& model) // :107-197
+    {
+        Mesh* mesh = object->getMesh();
+        const auto& vertices = mesh->getVertices(); const auto& indices = mesh->getIndices(); const auto& uvs = mesh->getUVCoords();
+        int closest = -1; vec3 bary{};
+        float minDistance = ray.didHit ? ray.hitInfo.distance : INFINITY;
+        auto vert = [&](int i) { return vec3{ vertices[(size_t)i * 3], vertices[(size_t)i * 3 + 1], vertices[(size_t)i * 3 + 2] }; };
+        for (int i = 0; i < mesh->getTriangleCount(); i++) {
+            const vec3 v0 = mulPoint(model, vert(indices[3 * i]), 1.0f), v1 = mulPoint(model, vert(indices[3 * i + 1]), 1.0f), v2 = mulPoint(model, vert(indices[3 * i + 2]), 1.0f);
+            vec3 bc{};
+            const float dist = distToTriangle(ray, v0, v1, v2, bc);
+            if (dist < minDistance) { minDistance = dist; closest = i; bary = bc; }
+        }
+        if (closest == -1) return;
+        const int i0 = indices[3 * closest], i1 = indices[3 * closest + 1], i2 = indices[3 * closest + 2];
+        const vec3 v0 = vert(i0), v1 = vert(i1), v2 = vert(i2);
+        auto uv = [&](int i, int c) { return uvs.empty() ? 0.0f : uvs[(size_t)i * 2 + c]; };
+        const float du1 = uv(i1, 0) - uv(i0, 0), dv1 = uv(i1, 1) - uv(i0, 1), du2 = uv(i2, 0) - uv(i0, 0), dv2 = uv(i2, 1) - uv(i0, 1);
+        const vec3 e1{ v1.x - v0.x, v1.y - v0.y, v1.z - v0.z }, e2{ v2.x - v0.x, v2.y - v0.y, v2.z - v0.z };
+        const float f = 1.0f / (du1 * dv2 - du2 * dv1);
+        const vec3 tg{ f * (dv2 * e1.x - dv1 * e2.x), f * (dv2 * e1.y - dv1 * e2.y), f * (dv2 * e1.z - dv1 * e2.z) };
+        const vec3 bt{ f * (-du2 * e1.x + du1 * e2.x), f * (-du2 * e1.y + du1 * e2.y), f * (-du2 * e1.z + du1 * e2.z) };
+        const vec3 T = normalize3(mulPoint(model, tg, 0.0f)), B = normalize3(mulPoint(model, bt, 0.0f));
+        const vec3 N = cross3(T, B);
+        vec3 ip{ (bary.x * v0.x + bary.y * v1.x) + bary.z * v2.x, (bary.x * v0.y + bary.y * v1.y) + bary.z * v2.y, (bary.x * v0.z + bary.y * v1.z) + bary.z * v2.z };
+        ray.didHit = true;
+        ray.hitInfo.hitPosition = mulPoint(model, ip, 1.0f);
+        ray.hitInfo.distance = minDistance;
+        ray.hitInfo.u = (bary.x * uv(i0, 0) + bary.y * uv(i1, 0)) + bary.z * uv(i2, 0);
+        ray.hitInfo.v = (bary.x * uv(i0, 1) + bary.y * uv(i1, 1)) + bary.z * uv(i2, 1);
+        ray.hitInfo.material = object->getMaterial();
+        ray.hitInfo.t = T; ray.hitInfo.b = B; ray.hitInfo.n = N;
+    }
+    float distToTriangle(const CRay& ray, vec3 v0, vec3 v1, vec3 v2, vec3& bc) const // :211-296; INFINITY = no hit
+    {
+        vec3 a{ v0.x - ray.origin.x, v0.y - ray.origin.y, v0.z - ray.origin.z }, b{ v1.x - ray.origin.x, v1.y - ray.origin.y, v1.z - ray.origin.z },
+            c{ v2.x - ray.origin.x, v2.y - ray.origin.y, v2.z - ray.origin.z };
+        const float ax = std::fabs(ray.direction.x), ay = std::fabs(ray.direction.y), az = std::fabs(ray.direction.z);
+        const int kz = ax > ay ? (ax > az ? 0 : 2) : (ay > az ? 1 : 2), kx = kz == 2 ? 0 : kz + 1, ky = kx == 2 ? 0 : kx + 1;
+        const float dx = comp(ray.direction, kx), dy = comp(ray.direction, ky), dz = comp(ray.direction, kz);
+        float p0x = comp(a, kx), p0y = comp(a, ky), p0z = comp(a, kz), p1x = comp(b, kx), p1y = comp(b, ky), p1z = comp(b, kz),
+              p2x = comp(c, kx), p2y = comp(c, ky), p2z = comp(c, kz);
+        const float sz = 1.f / dz, sx = -dx * sz, sy = -dy * sz;
+        p0x += sx * p0z; p0y += sy * p0z; p1x += sx * p1z; p1y += sy * p1z; p2x += sx * p2z; p2y += sy * p2z;
+        float e0 = p1x * p2y - p1y * p2x, e1 = p2x * p0y - p2y * p0x, e2 = p0x * p1y - p0y * p1x;
+        if (e0 == 0.0f || e1 == 0.0f || e2 == 0.0f) {
+            e0 = (float)((double)p2y * (double)p1x - (double)p2x * (double)p1y);
+            e1 = (float)((double)p0y * (double)p2x - (double)p0x * (double)p2y);
+            e2 = (float)((double)p1y * (double)p0x - (double)p1x * (double)p0y);
+        }
+        if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) return INFINITY;
+        const float det = e0 + e1 + e2;
+        if (det == 0) return INFINITY;
+        p0z *= sz; p1z *= sz; p2z *= sz;
+        const float tScaled = e0 * p0z + e1 * p1z + e2 * p2z;
+        if (det < 0 && (tScaled >= 0 || tScaled < maxDistance * det)) return INFINITY;
+        else if (det > 0 && (tScaled <= 0 || tScaled > maxDistance * det)) return INFINITY;
+        const float invDet = 1 / det;
+        bc = { e0 * invDet, e1 * invDet, e2 * invDet };
+        return tScaled * invDet;
+    }
+    static float randomValue(unsigned& seed) // :298-304
+    {
+        seed = seed * 747796405u + 2891336453u;
+        unsigned r = ((seed >> ((seed >> 28) + 4)) ^ seed) * 277803737u;
+        r = (r >> 22) ^ r;
+        return (float)(r / 4294967295.0);
+    }
+    static float randomNormal(unsigned& seed) // :306-312: theta through a binary64 product; log / sqrt / cos are the float overloads of <cmath>
+    {
+        const float theta = (float)(2 * 3.1415926 * randomValue(seed));
+        const float r = randomValue(seed);
+        const float rho = std::sqrt(-2 * std::log(r));
+        return rho * std::cos(theta);
+    }
+    static vec3 randomUnitVectorInHemisphere(unsigned& seed, vec3 n) // :315-332
+    {
+        const float x = randomNormal(seed), y = randomNormal(seed), z = randomNormal(seed);
+        const vec3 u = normalize3({ x, y, z });
+        return (u.x * n.x + u.y * n.y + u.z * n.z) > 0.0f ? u : vec3{ -u.x, -u.y, -u.z };
+    }
+    unsigned randomSeed = 0;
 };
 
 // ---------------------------------------------------------------- one host thread driving N contexts (SURVEY 8b "Threading", 8e)
