@@ -205,6 +205,15 @@ int rt_event_elapsed_ms(rt_ctx* ctx, int slot_begin, int slot_end, float* ms);
  * pow(x,5) / pow(x,1000) shortcuts of the shading code against ops 3 / 4 (input = high 16 bits of x; output = mismatch count) */
 int rt_detmath_eval(rt_ctx* ctx, int op, const float* in, int32_t n, float* out);
 
+/* stbi_load(path, &w, &h, &n, 0) / stbi_image_free of Texture::Texture (Material.cu:179, 195), host only (no context): decodes
+ * a PNG (8- or 16-bit samples, the latter reduced with >> 8; gray, gray+alpha, RGB, RGBA, 8-bit palette as RGB; not
+ * interlaced) or a baseline JPEG (stb_image's inverse DCT, chroma upsampling and colour conversion: the texel bytes are those
+ * the reference reads, raytracer_amd/host/rt_jpeg.hpp) into width*height*channels bytes, row 0 first, channels as stored
+ * (1, 2, 3 or 4).  Returns NULL for an unreadable or unsupported file (progressive JPEG, interlaced PNG, other formats).  The
+ * 4-channel expansion of Material.cu:184-197 stays with the caller, as in the reference. */
+uint8_t* rt_image_load(const char* path, int32_t* width, int32_t* height, int32_t* channels);
+void rt_image_free(uint8_t* pixels);
+
 const char* rt_version(void);
 
 #ifdef __cplusplus

@@ -62,7 +62,7 @@ EXPORTS = [
     "rt_material_update", "rt_material_destroy", "rt_object_create", "rt_object_destroy", "rt_scene_commit",
     "rt_camera_set_rays", "rt_framebuffer_create", "rt_framebuffer_wrap", "rt_framebuffer_destroy",
     "rt_framebuffer_read", "rt_framebuffer_write", "rt_present", "rt_srgb8_thresholds", "rt_framebuffer_enable_ids", "rt_framebuffer_read_ids",
-    "rt_render", "rt_render_bands", "rt_render_noalloc", "rt_trace_rays", "rt_event_record", "rt_event_elapsed_ms", "rt_detmath_eval", "rt_version",
+    "rt_image_load", "rt_image_free", "rt_render", "rt_render_bands", "rt_render_noalloc", "rt_trace_rays", "rt_event_record", "rt_event_elapsed_ms", "rt_detmath_eval", "rt_version",
 ]
 
 OPT_TRAVERSAL, OPT_COUNTERS, OPT_ACCUMULATE_STATS, OPT_WF_CHUNK, OPT_WF_LANES, OPT_BUILDER = 1, 2, 3, 4, 5, 6
@@ -107,6 +107,9 @@ def lib():
         L.rt_framebuffer_read_ids.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.rt_render.argtypes = [C.c_void_p, C.POINTER(CameraParams), C.POINTER(RendererParams), C.POINTER(SkyParams),
                                 Rect, C.c_int32]
+        L.rt_image_load.restype = C.POINTER(C.c_uint8)
+        L.rt_image_load.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.rt_image_free.argtypes = [C.POINTER(C.c_uint8)]
         L.rt_render_noalloc.argtypes = L.rt_render.argtypes
         L.rt_render_bands.argtypes = [C.c_void_p, C.POINTER(CameraParams), C.POINTER(RendererParams), C.POINTER(SkyParams),
                                       Rect, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
@@ -116,6 +119,19 @@ def lib():
         L.rt_detmath_eval.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int32, C.c_void_p]
         _LIB = L
     return _LIB
+
+
+def image_load(path):
+    """rt_image_load: HxWxC uint8 array of a PNG / baseline JPEG file (the reference's stbi_load bytes), or None."""
+    L = lib()
+    w, h, n = C.c_int32(), C.c_int32(), C.c_int32()
+    p = L.rt_image_load(str(path).encode(), C.byref(w), C.byref(h), C.byref(n))
+    if not p:
+        return None
+    try:
+        return np.ctypeslib.as_array(p, shape=(h.value, w.value, n.value)).copy()
+    finally:
+        L.rt_image_free(p)
 
 
 def _ptr(a):

@@ -3,6 +3,8 @@
 #include "../../include/rt_api.h"
 #include "rt_commit.h"
 #include "rt_detmath.h"
+#include "../host/rt_jpeg.hpp"
+#include "../host/rt_png.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -325,6 +327,20 @@ void launch_detmath(int op, const float* in, int n, float* out, hipStream_t stre
 } // namespace rt
 
 extern "C" {
+
+uint8_t* rt_image_load(const char* path, int32_t* width, int32_t* height, int32_t* channels)
+{
+    if (!path || !width || !height || !channels) return nullptr;
+    std::vector<unsigned char> pix; int w = 0, h = 0, n = 0;
+    if (!rth::png::decode(path, pix, w, h, n) && !rth::jpeg::decode(path, pix, w, h, n)) return nullptr;
+    uint8_t* out = (uint8_t*)malloc(pix.size() ? pix.size() : 1);
+    if (!out) return nullptr;
+    memcpy(out, pix.data(), pix.size());
+    *width = w; *height = h; *channels = n;
+    return out;
+}
+
+void rt_image_free(uint8_t* pixels) { free(pixels); }
 
 const char* rt_version(void) { return "raytracer_amd 0.2.0 (gfx950)"; }
 

@@ -88,9 +88,9 @@ int main(int argc, char** argv)
         return 0;
     }
     if (argc >= 3 && std::string(argv[1]) == "decode") {
-        // the host mirror's PNG decoder on a file: extents, channels and a CRC of the decoded bytes (CPU only)
+        // the host mirror's PNG / JPEG decoders on a file: extents, channels and a CRC of the decoded bytes (CPU only)
         std::vector<unsigned char> pix; int w = 0, h = 0, n = 0;
-        if (!png::decode(argv[2], pix, w, h, n)) { printf("refused\n"); return 0; }
+        if (!png::decode(argv[2], pix, w, h, n) && !jpeg::decode(argv[2], pix, w, h, n)) { printf("refused\n"); return 0; }
         printf("%d %d %d %lu\n", w, h, n, (unsigned long)crc32(0L, pix.data(), (uInt)pix.size()));
         return 0;
     }

@@ -65,9 +65,9 @@ TEXTURE_DECODES = 0                           # files actually decoded (tests: t
 
 
 class Texture:
-    """src/Material.hpp:17-50.  `Texture(path)` decodes with PIL (the reference uses stb_image: PNG texel
-    bytes are identical -- PNG is lossless, and a 16-bit PNG is reduced with >> 8 as stb_image.h:1198 does;
-    JPEG texels depend on the decoder and may differ by +-1) or wraps an already decoded HxWxC uint8 array.
+    """src/Material.hpp:17-50.  `Texture(path)` decodes with the library's rt_image_load (include/rt_api.h: PNG, and
+    baseline JPEG with stb_image's arithmetic, so the texel bytes are what the reference's stbi_load gives -- pinned
+    against that stb_image itself in tests/test_texture_decode.py) or wraps an already decoded HxWxC uint8 array.
     Textures are shared by path as in the reference (src/Material.cu:165-178): a second Texture of a path
     that is still alive decodes nothing and flattens to the same device texture."""
 
@@ -87,19 +87,11 @@ class Texture:
             _TEXTURE_MAP[self.path] = self._store
             TEXTURE_DECODES += 1
             try:
-                from PIL import Image
-
-                im = Image.open(self.path)
-                if im.mode in ("I;16", "I;16B", "I"):
-                    arr = (np.asarray(im).astype(np.uint32) >> 8).astype(np.uint8)  # stb: >>8
-                elif im.mode in ("L", "LA", "RGB", "RGBA"):
-                    arr = np.asarray(im)
-                elif im.mode == "P":
-                    arr = np.asarray(im.convert("RGBA" if "transparency" in im.info else "RGB"))
-                else:
-                    arr = np.asarray(im.convert("RGB"))
-                self._store.rgba8 = expand_to_rgba8(arr)
-                self._store.loadSuccess = True
+                from . import capi   # late: capi imports this module
+                arr = capi.image_load(self.path)
+                if arr is not None:
+                    self._store.rgba8 = expand_to_rgba8(arr)
+                    self._store.loadSuccess = True
             except Exception:
                 self._store.loadSuccess = False
 

@@ -3,10 +3,11 @@
 
 Pinning: oracle/_ref/libstbi_ref.so is the reference's own vendored decoder (src/stb_image.h v2.28) compiled from
 where it lies by `make -C oracle ref`.  When the reference checkout and that build are present (this container),
-every PNG the reference ships is decoded three ways -- stb_image, the Python mirror (PIL) and the C++ mirror's own
-codec -- and the bytes must be identical, 16-bit files included (stb reduces with >> 8, stb_image.h:1198).  JPEG texels
-depend on the decoder (PIL vs stb: <= 3 levels on <= 0.4 % of the bytes of the reference's files): the C++ mirror refuses
-JPEG, the Python mirror decodes it with PIL, and scenes.py binds none of the reference's JPEG maps."""
+every PNG and JPEG the reference ships is decoded by stb_image, by the library's rt_image_load (what the Python
+mirror's Texture(path) calls) and by the C++ mirror, and the bytes must be identical: 16-bit PNGs included (stb reduces
+with >> 8, stb_image.h:1198), and JPEG, where the decoder shows in the bytes (PIL differs from stb by up to 3 levels on
+these files), through a decoder that makes stb_image's fixed-point choices (raytracer_amd/host/rt_jpeg.hpp).  JPEGs written
+here with other sampling factors, qualities, restart intervals and optimised tables are compared the same way."""
 import ctypes as C
 import glob
 import os
@@ -61,25 +62,40 @@ def test_sixteen_bit_png_is_reduced_with_shift_8(tmp_path):
     assert tuple(Texture(str(tmp_path / "g16.png")).rgba8[0, :4, 0]) == (0, 1, 128, 255)
 
 
-@pytest.mark.skipif(not (os.path.isdir(REF_RES) and os.path.exists(STB)), reason="needs the reference checkout and `make -C oracle ref`")
-def test_reference_pngs_decode_like_the_references_own_stb_image():
+def stb_load(path):
     L = C.CDLL(STB)
     L.stbi_load.restype = C.POINTER(C.c_ubyte)
     L.stbi_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
     L.stbi_image_free.argtypes = [C.c_void_p]
-    files = sorted(glob.glob(REF_RES + "/**/*.png", recursive=True))
-    assert len(files) >= 12
+    w, h, n = C.c_int(), C.c_int(), C.c_int()
+    p = L.stbi_load(path.encode(), C.byref(w), C.byref(h), C.byref(n), 0)     # Material.cu:179: stbi_load(path, ..., 0)
+    if not p:
+        return None
+    ref = np.ctypeslib.as_array(p, shape=(h.value, w.value, n.value)).copy()
+    L.stbi_image_free(p)
+    return ref
+
+
+def same_as_stb(f):
+    from raytracer_amd import capi
+    ref = stb_load(f)
+    assert ref is not None, f
+    got = capi.image_load(f)
+    assert got is not None and np.array_equal(got, ref), f                                          # rt_image_load
+    t = Texture(f)
+    assert t.getLoadSuccess() and np.array_equal(t.rgba8, expand_to_rgba8(ref)), f                  # Python mirror, after the 4-channel expansion
+    assert cpp_decode(f) == (ref.shape[1], ref.shape[0], ref.shape[2], zlib.crc32(ref.tobytes())), f  # C++ mirror
+
+
+@pytest.mark.skipif(not (os.path.isdir(REF_RES) and os.path.exists(STB)), reason="needs the reference checkout and `make -C oracle ref`")
+def test_reference_textures_decode_like_the_references_own_stb_image():
+    pngs = sorted(glob.glob(REF_RES + "/**/*.png", recursive=True))
+    jpgs = sorted(glob.glob(REF_RES + "/**/*.jp*g", recursive=True))
+    assert len(pngs) >= 12 and len(jpgs) >= 14
     sixteen = 0
-    for f in files:
-        w, h, n = C.c_int(), C.c_int(), C.c_int()
-        p = L.stbi_load(f.encode(), C.byref(w), C.byref(h), C.byref(n), 0)     # Material.cu:179: stbi_load(path, ..., 0)
-        assert p, f
-        ref = np.ctypeslib.as_array(p, shape=(h.value, w.value, n.value)).copy()
-        L.stbi_image_free(p)
-        t = Texture(f)
-        assert t.getLoadSuccess() and np.array_equal(t.rgba8, expand_to_rgba8(ref)), f      # Python mirror, after the 4-channel expansion
-        assert cpp_decode(f) == (w.value, h.value, n.value, zlib.crc32(ref.tobytes())), f    # C++ mirror
-        sixteen += struct.unpack(">B", open(f, "rb").read(25)[24:25])[0] == 16
+    for f in pngs + jpgs:
+        same_as_stb(f)
+        sixteen += f.endswith(".png") and struct.unpack(">B", open(f, "rb").read(25)[24:25])[0] == 16
     assert sixteen >= 2   # Base_Color (RGB16) and Displacement (gray16) are among them
     # the fixture the GPU box renders with holds the same bytes
     fx = os.path.join(ROOT, "tests", "golden", "ref_assets.npz")
@@ -89,13 +105,39 @@ def test_reference_pngs_decode_like_the_references_own_stb_image():
             assert np.array_equal(expand_to_rgba8(z[key]), Texture(REF_RES + "/" + rel).rgba8)
 
 
-def test_jpeg_is_refused_by_the_cpp_mirror_and_decoded_by_the_python_one(tmp_path):
+@pytest.mark.skipif(not os.path.exists(STB), reason="needs `make -C oracle ref` (the reference checkout)")
+def test_written_jpegs_decode_like_stb_image(tmp_path):
+    """Sampling 4:4:4 / 4:2:2 / 4:2:0, gray, two qualities, restart intervals, optimised Huffman tables, odd extents."""
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    noise = (rng.random((61, 83, 3)) * 255).astype(np.uint8)
+    smooth = np.clip(np.cumsum(rng.normal(0, 6, (120, 177, 3)), axis=1) + 128, 0, 255).astype(np.uint8)
+    k = 0
+    for im in (noise, smooth):
+        for ss in (0, 1, 2):
+            for q in (35, 90):
+                f = str(tmp_path / f"t{k}.jpg"); k += 1
+                Image.fromarray(im).save(f, quality=q, subsampling=ss)
+                same_as_stb(f)
+    Image.fromarray(smooth[..., 0]).save(str(tmp_path / "g.jpg"), quality=80)
+    Image.fromarray(smooth).save(str(tmp_path / "r.jpg"), quality=80, subsampling=2, restart_marker_blocks=3)
+    Image.fromarray(smooth).save(str(tmp_path / "o.jpg"), quality=80, optimize=True, subsampling=1)
+    Image.fromarray(smooth[:1, :1]).save(str(tmp_path / "one.jpg"), quality=80)
+    for name in ("g.jpg", "r.jpg", "o.jpg", "one.jpg"):
+        same_as_stb(str(tmp_path / name))
+
+
+def test_jpeg_loads_in_both_mirrors_and_unsupported_files_are_refused(tmp_path):
     from PIL import Image
     img = (np.random.default_rng(2).random((32, 48, 3)) * 255).astype(np.uint8)
     Image.fromarray(img).save(str(tmp_path / "a.jpg"), quality=90)
-    assert cpp_decode(str(tmp_path / "a.jpg")) is None
+    assert cpp_decode(str(tmp_path / "a.jpg"))[:3] == (48, 32, 3)
     t = Texture(str(tmp_path / "a.jpg"))
-    assert t.getLoadSuccess() and t.rgba8.shape == (32, 48, 4)
+    assert t.getLoadSuccess() and t.rgba8.shape == (32, 48, 4) and np.abs(t.rgba8[..., :3].astype(int) - np.asarray(Image.open(str(tmp_path / "a.jpg"))).astype(int)).max() <= 4   # libjpeg is close, not equal
+    Image.fromarray(img).save(str(tmp_path / "p.jpg"), quality=90, progressive=True)
+    (tmp_path / "junk.png").write_bytes(b"\x89PNG\r\n\x1a\n" + b"\x00" * 40)
+    for bad in ("p.jpg", "junk.png", "missing.png"):   # progressive JPEG, broken PNG, no file: refused, never a crash
+        assert cpp_decode(str(tmp_path / bad)) is None and not Texture(str(tmp_path / bad)).getLoadSuccess()
     m = Material("m")
     assert m.setAlbedoTexture(str(tmp_path / "a.jpg")) and not m.setAlbedoTexture(str(tmp_path / "missing.png"))
     assert m.albedoTexture is not None   # a failed load keeps the old texture (setTextureRef, Material.cu:113-130)
