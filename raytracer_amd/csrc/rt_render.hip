@@ -930,7 +930,7 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
             // launch, which traces it with the exact in-order emulation inline (6e-6 of the rays on C2 / C4, 4e-4 on C5;
             // a pass per level over a list of such rays cost four near-empty launches per frame, 0.12 ms of C2's 6.8)
             bool band = false;
-            const Hit h = trav_result(T, ray, band);
+            const Hit h = trav_result(T, ray, band, a.scene.bandRel);
             const bool over = stack.dropped;
             stack.dropped = false;
             if (band) st.slow++;
@@ -941,7 +941,7 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
                 band = false;
             }
 #endif
-            w.hitA[hitPos] = make_float4(h.t, h.b0, h.b1, h.b2);
+            if (h.gid != kNoHit) w.hitA[hitPos] = make_float4(h.t, h.b0, h.b1, h.b2); // a miss has nothing to say here: 16 bytes less per sky ray
             w.hitM[hitPos] = make_uint2((h.gid == kNoHit ? kWfMiss : h.gid) | (over || band ? kWfDanger : 0u), T.bestObj);
             have = false;
         }
@@ -1129,7 +1129,7 @@ __global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const R
                         const float4* tp = reinterpret_cast<const float4*>(a.scene.triLeaf + T.triBase + first + q);
                         const float4 A = tp[0], B = tp[1], C = tp[2];
                         st.bvh.tris += active ? 1u : 0u;
-                        trav_test_triangle(T, A, B, C);
+                        trav_test_triangle(T, A, B, C, a.scene.bandRel);
                     }
                     if (sp == 0) break;
                     node = __builtin_amdgcn_readlane((int)stk, --sp);
@@ -1141,7 +1141,7 @@ __global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const R
 #endif
         if (active) {
             bool band = false;
-            const Hit hres = trav_result(T, ray, band);
+            const Hit hres = trav_result(T, ray, band, a.scene.bandRel);
             const uint32_t hitPos = (uint32_t)wf_hit_pos(w, blockStripe, off + (uint32_t)lane);
             if (band) st.slow++;
 #if RT_EXACT_PASS
@@ -1150,7 +1150,7 @@ __global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const R
                 band = false;
             }
 #endif
-            w.hitA[hitPos] = make_float4(hres.t, hres.b0, hres.b1, hres.b2);
+            if (hres.gid != kNoHit) w.hitA[hitPos] = make_float4(hres.t, hres.b0, hres.b1, hres.b2);
             w.hitM[hitPos] = make_uint2((hres.gid == kNoHit ? kWfMiss : hres.gid) | (overflow || band ? kWfDanger : 0u), T.bestObj);
         }
 #ifdef RT_PHASE_TIMERS

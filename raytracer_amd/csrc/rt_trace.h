@@ -654,7 +654,7 @@ struct Trav {
     int32_t node;
     uint32_t triFirst, triCount, triBase;
     int sp;
-    float bound, m0, rayScale, bandRel;
+    float bound, m0, rayScale;
     Hit best;
     uint32_t bestObj;
     float otherT;
@@ -669,7 +669,6 @@ __device__ __forceinline__ void trav_init(Trav& T, const SceneView& s, const Ray
     T.br = make_box_ray(ray, s.sceneMaxAbs);
     T.rayScale = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ray.ox), __builtin_fabsf(ray.oy)),
                                  __builtin_fmaxf(__builtin_fabsf(ray.oz), s.sceneMaxAbs));
-    T.bandRel = s.bandRel;
     T.m0 = ray.maxDist; T.bound = ray.maxDist;
     T.best.t = FLT_MAX; T.best.gid = kNoHit; T.best.b0 = T.best.b1 = T.best.b2 = 0.0f;
     T.bestObj = kNoHit; T.otherT = FLT_MAX;
@@ -704,7 +703,7 @@ __device__ __forceinline__ void trav_take_leaf(Trav& T, const SceneView& s, HS& 
 // The object-space cull of the winner's object (GPURaytracer.cu:267-315) is checked once, by the
 // shading side: a hit on an object whose cull fails (flat meshes) sends the pixel to the
 // redo launch instead of costing every triangle step a 96-byte fetch and a slab test.
-__device__ __forceinline__ void trav_test_triangle(Trav& T, const float4& A, const float4& B, const float4& C)
+__device__ __forceinline__ void trav_test_triangle(Trav& T, const float4& A, const float4& B, const float4& C, const float bandRel)
 {
     float t, b0, b1, b2;
     if (tri_test_rot(T.q, T.m0, A, B, C, t, b0, b1, b2) && t <= T.bound) {
@@ -716,7 +715,7 @@ __device__ __forceinline__ void trav_test_triangle(Trav& T, const float4& A, con
         }
         if (better) {
             T.best.t = t; T.best.b0 = b0; T.best.b1 = b1; T.best.b2 = b2; T.best.gid = gid;
-            T.bound = __builtin_fminf(T.m0, t + band_of(t, T.rayScale, T.bandRel));
+            T.bound = __builtin_fminf(T.m0, t + band_of(t, T.rayScale, bandRel));
         }
     }
 }
@@ -729,7 +728,7 @@ __device__ __forceinline__ void trav_tri_step(Trav& T, const SceneView& s, const
         const float4 A = p[0], B = p[1], C = p[2];
         T.triFirst++; T.triCount--;
         cnt.tris++;
-        trav_test_triangle(T, A, B, C);
+        trav_test_triangle(T, A, B, C, s.bandRel);
     }
     trav_take_leaf(T, s, stack);
 }
@@ -785,10 +784,10 @@ __device__ __forceinline__ void trav_burst(Trav& T, const SceneView& s, const Ra
 }
 
 // Closest hit of a finished traversal; `danger` = another object has a hit inside the tie band.
-__device__ __forceinline__ Hit trav_result(const Trav& T, Ray& ray, bool& danger)
+__device__ __forceinline__ Hit trav_result(const Trav& T, Ray& ray, bool& danger, const float bandRel)
 {
     if (T.best.gid != kNoHit) {
-        const float limit = T.best.t + band_of(T.best.t, T.rayScale, T.bandRel);
+        const float limit = T.best.t + band_of(T.best.t, T.rayScale, bandRel);
         if (T.otherT <= limit) danger = true;
         ray.maxDist = T.best.t;
     }
@@ -802,7 +801,7 @@ __device__ __forceinline__ Hit trav_finish(Trav& T, const SceneView& s, Ray& ray
         cull_lookup(s, ray, T.bestObj, T.cc);
         if (!object_cull_pass(T.cc.tmin, T.cc.bfar, T.m0)) danger = true;
     }
-    return trav_result(T, ray, danger);
+    return trav_result(T, ray, danger, s.bandRel);
 }
 
 } // namespace rt

@@ -1,0 +1,26 @@
+#!/bin/bash
+# The round's profile set (run on the GPU box through gpurun): tools/profile_round.sh TAG
+#   gpurun_out/TAG_bench.json                     python bench.py (C2 headline + C4 under "also")
+#   gpurun_out/TAG_{c2,c4,c5}_kstats.txt          rocprofv3 --kernel-trace --stats: per-kernel totals + last frame's launches
+#   gpurun_out/TAG_{c2,c4}_pmc.json/_levels.txt   rocprofv3 --pmc passes (tools/pmc.sh), per kernel and per launch
+#   gpurun_out/TAG_traffic.json                   HBM bytes per rt_render from the FETCH_SIZE / WRITE_SIZE passes
+tag=$1
+set -o pipefail
+timeout -k 10 300 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || exit 1
+for w in c3 c5; do
+  timeout -k 10 300 python bench.py --workload $w --also "" --steps 5 > gpurun_out/${tag}_bench_$w.json 2>> gpurun_out/${tag}_bench.err || exit 1
+done
+for w in c2 c4 c5; do
+  extra="--workload $w"; [ $w = c5 ] && extra="$extra --steps 2"
+  rm -rf gpurun_out/ks_${tag}_$w
+  bash tools/kstats.sh ${tag}_$w $extra > gpurun_out/${tag}_${w}_kstats.txt 2>&1 || exit 1
+  cp gpurun_out/ks_${tag}_$w/*/*_kernel_stats.csv gpurun_out/${tag}_${w}_kernel_stats.csv
+done
+for w in c2 c4; do
+  rm -rf gpurun_out/pmc_${tag}_$w
+  bash tools/pmc.sh gpurun_out/pmc_${tag}_$w --workload $w > gpurun_out/${tag}_${w}_pmc.txt 2>&1 || exit 1
+  cp gpurun_out/pmc_${tag}_$w/summary.json gpurun_out/${tag}_${w}_pmc.json
+  python3 tools/pmc_levels.py gpurun_out/pmc_${tag}_$w > gpurun_out/${tag}_${w}_pmc_levels.txt
+  python3 tools/traffic.py gpurun_out/pmc_${tag}_$w $w 3 > gpurun_out/${tag}_${w}_traffic.json
+done
+echo done

@@ -9,14 +9,21 @@ per_kernel = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in glob.glob(root + "/pass*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
-        if not (k.startswith("rt::wf_") or "render_kernel" in k or "path_kernel" in k):
+        if not ("rt::wf_" in k or "render_kernel" in k or "path_kernel" in k):
             continue
         if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
             tot[r["Counter_Name"]] += float(r["Counter_Value"])
             per_kernel[k][r["Counter_Name"]] += float(r["Counter_Value"])
 fetch = tot["FETCH_SIZE"] * 1024.0 * 2.0 / frames
 write = tot["WRITE_SIZE"] * 1024.0 / frames
-out = {"workload": workload, "frames": frames, "hbm_bytes_per_launch": fetch + write,
+import ctypes, os
+try:
+    _L = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracer_amd", "librt_amd.so"))
+    _L.rt_version.restype = ctypes.c_char_p
+    lib = _L.rt_version().decode()
+except OSError:
+    lib = None
+out = {"workload": workload, "lib": lib, "frames": frames, "hbm_bytes_per_launch": fetch + write,
        "fetch_bytes_per_launch_corrected_x2": fetch, "write_bytes_per_launch": write,
        "launch": "one rt_render call = every kernel of one frame",
        "per_kernel_bytes_per_frame": {k: {"fetch_x2": v["FETCH_SIZE"] * 2048.0 / frames, "write": v["WRITE_SIZE"] * 1024.0 / frames}
