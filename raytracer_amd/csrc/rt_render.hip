@@ -1338,8 +1338,8 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <bool DEAL>
-__global__ __launch_bounds__(256, RT_SHADE_OCC) void wf_shade_kernel(const RenderArgs a, const WfBufs w, const int level)
+template <bool DEAL> // queue order: 5 waves per SIMD (96 VGPRs, 5 spilled: 1.26 -> 1.23 ms on C2); dealt: 4 (at 5 it spills 39 and loses)
+__global__ __launch_bounds__(256, DEAL ? RT_SHADE_OCC : RT_SHADE_OCC + 1) void wf_shade_kernel(const RenderArgs a, const WfBufs w, const int level)
 {
     __shared__ uint32_t wgCnt[8];
     LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
