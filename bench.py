@@ -75,9 +75,17 @@ class Job:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         if self.world != args.gpus and self.world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with torch.distributed.run (see the task contract)")
+        # RT_BENCH_REHEARSE=1: every rank on GPU 0 with gloo collectives -- a rehearsal of the N > 1 code paths on a one-GPU
+        # box (RCCL refuses two ranks on one device); its timings mean nothing
+        self.rehearse = bool(os.environ.get("RT_BENCH_REHEARSE"))
+        if self.rehearse:
+            self.local_rank = 0
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            if self.rehearse:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
         torch.cuda.set_device(self.local_rank)

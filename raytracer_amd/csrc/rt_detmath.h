@@ -5,7 +5,8 @@
 // NVIDIA hardware, and a one-ulp difference in a bounce direction can flip a hit at 1 spp, so
 // this build defines its own: fixed polynomials evaluated in binary64 with separate multiply
 // and add (the library is compiled with -ffp-contract=off), rounded once to binary32.  The
-// results agree with correctly rounded libm values (tests/test_detmath_gpu.py).  MI355X runs
+// results agree with correctly rounded libm values, and bit for bit with the oracle's (oracle/oracle_math.h;
+// tests/test_parity_gpu.py::test_detmath_matches_oracle_bit_for_bit).  MI355X runs
 // FP64 vector math at half the FP32 rate, so these cost little next to traversal.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -77,9 +78,6 @@ __device__ __forceinline__ float rsqrt_f(float x) { return 1.0f / __builtin_sqrt
 
 __device__ __forceinline__ float log_f(float x)
 {
-#ifdef RT_ABLATE_MATH
-    return x * 0.5f - 1.0f; // timing-only build, wrong on purpose
-#endif
     if (x != x) return x;
     if (x < 0.0f) return __builtin_nanf("");
     if (x == 0.0f) return -__builtin_inff();
@@ -89,9 +87,6 @@ __device__ __forceinline__ float log_f(float x)
 
 __device__ __forceinline__ float exp_f(float x)
 {
-#ifdef RT_ABLATE_MATH
-    return x * 0.25f + 0.5f;
-#endif
     if (x != x) return x;
     if (x > 89.0f) return __builtin_inff();
     if (x < -104.0f) return 0.0f;
@@ -100,9 +95,6 @@ __device__ __forceinline__ float exp_f(float x)
 
 __device__ __forceinline__ float cos_f(float x)
 {
-#ifdef RT_ABLATE_MATH
-    return x * 0.1f - 0.3f;
-#endif
     if (x != x || x == __builtin_inff() || x == -__builtin_inff()) return __builtin_nanf("");
     const double xd = (double)x;
     const double kf = floor(xd * kTwoOverPi + 0.5);
@@ -139,9 +131,6 @@ __device__ __forceinline__ float cos_f(float x)
 
 __device__ __forceinline__ float pow_f(float x, float y)
 {
-#ifdef RT_ABLATE_MATH
-    return x * x * y * 1e-3f;
-#endif
     if (x != x || y != y) return __builtin_nanf("");
     if (y == 0.0f) return 1.0f;
     if (x < 0.0f) return __builtin_nanf("");

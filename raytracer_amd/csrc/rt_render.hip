@@ -288,14 +288,12 @@ __device__ __forceinline__ bool shade_segment(const RenderArgs& a, const Hit& h,
 #ifndef RT_DIAG_EXACT
     st.hits++;
 #endif
-#ifndef RT_ABLATE_CULL
     if (cullObj != kNoHit) {
         const ObjCull o = load_obj(a.scene.objects + cullObj);
         float tmin, bfar;
         object_slab(ray, o, tmin, bfar);
         if (!object_cull_pass(tmin, bfar, cullMax)) *cullFail = true;
     }
-#endif
     const Surface sf = shade_surface(a.scene, h, ho, hm, ht, matHint);
     checksum += seg_hash(ho, hm, ht, sample, (uint32_t)i);
     if (i == 0 && sample == 0) { primary[0] = ho; primary[1] = hm; primary[2] = ht; }
@@ -757,7 +755,7 @@ __global__ __launch_bounds__(256) void trace_rays_kernel(SceneView s, const floa
 // the traversal loops run at the occupancy the shading code's registers allow (168 VGPRs, 3 waves
 // per SIMD) and the shading code runs behind the traversal's live state; measured, both halves were
 // bound by the latency of dependent fetches at that occupancy.  Here the path state lives in HBM
-// (288 GB: 100 bytes per sample in flight is nothing) and each bounce level is two launches:
+// (288 GB: ~190 bytes per sample in flight is nothing) and each bounce level is two launches:
 //   wf_trace: persistent, closest-hit queries only, lanes refilled from the level's queue;
 //   wf_shade: one lane per live path, full waves, material fetches batched.
 // The per-sample results are summed per pixel in the reference's order by wf_resolve.
@@ -1269,9 +1267,6 @@ __device__ __forceinline__ void shade_entry(const RenderArgs& a, const WfBufs& w
     PathAcc acc; acc.ox = aO.x; acc.oy = aO.y; acc.oz = aO.z; acc.bx = aB.x; acc.by = aB.y; acc.bz = aB.z;
     Hit h; h.t = 0.0f; h.b0 = h.b1 = h.b2 = 0.0f;
     h.gid = (hM.x & kWfMiss) == kWfMiss ? kNoHit : (hM.x & kWfMiss);
-#if defined(RT_ABL_SHADE) && (RT_ABL_SHADE & 2)
-    if (level > 0) h.gid = kNoHit; // timing only: every entry takes the sky path
-#endif
     bool danger = (hM.x & kWfDanger) != 0u;
     uint32_t cullObj = kNoHit;
     float m0 = 0.0f;
@@ -1297,18 +1292,12 @@ __device__ __forceinline__ void shade_entry(const RenderArgs& a, const WfBufs& w
     if (o.more) { // kept in registers until the survivors' positions are known
         o.ray = ray; o.seed = seed; o.chk = checksum; o.acc = acc;
     } else
-#if defined(RT_ABL_SHADE) && (RT_ABL_SHADE & 1)
-    if (level == 0) // timing only: no result stores past the camera rays
-#endif
     { // exposureCorrection (:690-698), per sample
         const size_t oi = wf_out_index(pix, sidx, spp);
         w.out[oi] = make_float4(1.0f - rtd::exp_f(-acc.ox * a.exposure), 1.0f - rtd::exp_f(-acc.oy * a.exposure),
                                 1.0f - rtd::exp_f(-acc.oz * a.exposure), __uint_as_float(checksum));
         w.outRays[oi] = (uint8_t)(level + 1 > 255 ? 255 : level + 1);
     }
-#if defined(RT_ABL_SHADE) && (RT_ABL_SHADE & 4)
-    if (level > 0) o.more = false; // timing only: no survivors
-#endif
 }
 
 // survivors go to the same stripe of the next level's queue: one atomic per wave
