@@ -39,8 +39,8 @@ NODE_B, TRI_B = 64.0, 48.0                 # one four-wide BVH node; 3 x i32 + 3
 HIT_B, MAP_B = 12.0 + 96.0, 16.0           # per shaded hit: 3 indices + 3 x (12 + 12 + 8) B attributes; 4 texels x 4 B per bound map
 NODE_F, TRI_F, HIT_F = 30.0, 45.0, 300.0   # flop per node test / triangle test / shaded hit (8d)
 # path state crossing HBM between the launches of the wavefront pipeline, per closest-hit query (not algorithmic):
-# trace: ray 32 + queue 4 in, hit 20 out; shade: ray 32 + hit 20 + state 32 + queue 4 in, ray 32 + state 32 + queue 4 out
-STATE_B = (32 + 4 + 20) + (32 + 20 + 32 + 4) + (32 + 32 + 4)
+# trace: ray 32 in, hit 24 out; shade: ray 32 + hit 24 + state 32 in, ray 32 + state 32 out (the slot rides in the state record)
+STATE_B = (32 + 24) + (32 + 24 + 32) + (32 + 32)
 
 
 def build_workload(name, args):

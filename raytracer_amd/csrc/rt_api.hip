@@ -175,8 +175,8 @@ float band_rel_of(const float* model16, const float* inv16, int n)
     return (float)std::max(2e-4, rel);
 }
 
-// Lays one lane's wavefront workspace out in [base, base + return value): ~185 bytes per sample in flight
-// (path state of both ping-pong halves 128, hit 24, result 17, queue 8, pixel flag + redo list 8).
+// Lays one lane's wavefront workspace out in [base, base + return value): ~177 bytes per sample in flight
+// (path state of both ping-pong halves 128, hit 24, result 17, pixel flag + redo list 8).
 // base == nullptr: sizing only.  Every array starts on a 256-byte boundary.
 size_t wf_carve(uint8_t* base, size_t slots, int levels, rt::WfBufs& w)
 {
@@ -200,7 +200,6 @@ size_t wf_carve(uint8_t* base, size_t slots, int levels, rt::WfBufs& w)
     w.outRays = (uint8_t*)take(slots);
     w.pixFlag = (uint32_t*)take(4 * ((slots + 63) & ~(size_t)63));
     w.redoList = (uint32_t*)take(4 * ((slots + 63) & ~(size_t)63));
-    w.queue = (uint32_t*)take(4 * queueWords);
     w.exactList = (uint32_t*)take(4 * (queueWords / 2));
     w.ctrl = (uint32_t*)take(4 * rt::wf_ctrl_words(levels));
     return off;

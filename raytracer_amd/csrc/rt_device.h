@@ -139,7 +139,6 @@ struct WfBufs {
     uint8_t* outRays;    // [slot] closest-hit queries of the finished sample
     uint32_t* pixFlag;   // [pixelInChunk] != 0: flagged for the redo launch
     uint32_t* redoList;  // [pixelInChunk] the chunk's flagged pixels (a lane's chunks run one after the other, so they share it)
-    uint32_t* queue;     // [2][kWfStripes][subCap] slots, ping-pong over levels
     uint32_t* exactList; // [kWfStripes][subCap] hit positions of the level's rays inside the tie band, listed per stripe (RT_EXACT_PASS)
     uint32_t* ctrl;      // [level][2][kWfStripes][kWfCtrlStride]: counts, cursors; then the redo count; then per level one tie-band count per stripe
     uint32_t subCap;

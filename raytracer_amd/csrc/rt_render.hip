@@ -804,7 +804,13 @@ __device__ __forceinline__ bool wf_pixel(const RenderArgs& a, const WfBufs& w, u
     return x < a.x1 && y < a.y1;
 }
 
-// level 0: camera rays (:140-163), path state, queue 0 (identity order, holes for pixels outside)
+// slot of entry `off` of a stripe at level 0: wf_gen lays the slots out piece by piece (piece = 256 consecutive slots,
+// piece p in stripe p % kWfStripes), so no queue array is kept for the camera rays; at the levels past them the slot
+// travels in the spare word of the beta record
+__device__ __forceinline__ uint32_t wf_level0_slot(uint32_t stripe, uint32_t off) { return ((off >> 8) * kWfStripes + stripe) * 256u + (off & 255u); }
+__device__ __forceinline__ bool wf_is_hole(const float4& d) { return d.x == 0.0f && d.y == 0.0f && d.z == 0.0f; }
+
+// level 0: camera rays (:140-163) in slot order; holes for pixels outside the rectangle
 __global__ __launch_bounds__(256) void wf_gen_kernel(const RenderArgs a, const WfBufs w)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -815,7 +821,7 @@ __global__ __launch_bounds__(256) void wf_gen_kernel(const RenderArgs a, const W
         *wf_count(w, 0, (int)s) = pieces * 256u;
     }
     const uint32_t piece = blockIdx.x, stripe = piece % kWfStripes, off = (piece / kWfStripes) * 256u + threadIdx.x;
-    uint32_t entry = kWfHole;
+    float4 entry = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // a hole (pixel outside the rectangle, or no bounce loop): the zero direction
     if (i < w.nSlots) {
         const uint32_t spp = a.sampleCount;
         const uint32_t pix = i / spp, sidx = i - pix * spp;
@@ -824,9 +830,8 @@ __global__ __launch_bounds__(256) void wf_gen_kernel(const RenderArgs a, const W
             if (sidx == 0) w.pixFlag[pix] = 0u;
             uint32_t seed = sample_seed(a, x, y, sidx);
             const Ray ray = setup_ray(a, x, y, seed);
-            if (a.bounceCount > 0) {
-                w.rayD[wf_pos(w, 0, stripe, off)] = make_float4(ray.dx, ray.dy, ray.dz, __uint_as_float(seed));
-                entry = i; // outgoing light 0, beta 1, checksum 0: wf_shade(0) supplies them
+            if (a.bounceCount > 0) { // outgoing light 0, beta 1, checksum 0 and the slot (wf_level0_slot): wf_shade(0) supplies them
+                entry = make_float4(ray.dx, ray.dy, ray.dz, __uint_as_float(seed));
             } else { // the bounce loop does not run: radiance 0 (:172)
                 if (sidx == 0 && a.ids) {
                     uint32_t* idp = reinterpret_cast<uint32_t*>(a.ids + ((size_t)y * (size_t)a.width + (size_t)x));
@@ -838,7 +843,7 @@ __global__ __launch_bounds__(256) void wf_gen_kernel(const RenderArgs a, const W
             }
         }
     }
-    w.queue[wf_pos(w, 0, stripe, off)] = entry;
+    w.rayD[wf_pos(w, 0, stripe, off)] = entry;
 }
 
 #ifndef RT_WF_OCC
@@ -909,7 +914,7 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
         if (nxtHas) {
             const size_t p = wf_pos(w, level, stripe, off + (uint32_t)lane);
             const bool in = (uint32_t)lane < n;
-            nSlot = in ? w.queue[p] : kWfHole;
+            nSlot = in ? 0u : kWfHole;   // no holes past the camera rays
             if (in) { nO = wf_ray_origin(a, w, level, p); nD = w.rayD[p]; }
             nOff = (uint32_t)wf_hit_pos(w, stripe, off + (uint32_t)lane);
             issue_claim();
@@ -1052,11 +1057,11 @@ __global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const R
 #endif
         issue_claim();
         const size_t p = wf_pos(w, level, blockStripe, off + (uint32_t)lane);
-        const uint32_t slot = (uint32_t)lane < n ? w.queue[p] : kWfHole;
-        const bool active = slot != kWfHole;
+        const float4 d = (uint32_t)lane < n ? w.rayD[p] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const bool active = !wf_is_hole(d);
         Ray ray; ray.ox = ray.oy = ray.oz = 0.0f; ray.dx = 1.0f; ray.dy = ray.dz = 0.0f; ray.maxDist = -1.0f;
         if (active) {
-            const float4 o = wf_ray_origin(a, w, level, p), d = w.rayD[p];
+            const float4 o = wf_ray_origin(a, w, level, p);
             ray.ox = o.x; ray.oy = o.y; ray.oz = o.z; ray.maxDist = o.w; ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
         }
         Trav T; trav_init(T, a.scene, ray); // a lane without a ray has bound -1: it enters no box and accepts no hit
@@ -1156,7 +1161,7 @@ __global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const R
             st.bvh.idleA += (uint32_t)((tk2 - tk1) >> 6); st.bvh.idleB += (uint32_t)((clock64() - tk2) >> 6);
             st.bvh.diagA += (uint32_t)((tk1 - tk0) >> 6); st.slow++;
             if (tk2 - tk1 > (1ll << 22)) {
-                int px, py; wf_pixel(a, w, slot / a.sampleCount, px, py);
+                int px, py; wf_pixel(a, w, wf_level0_slot(blockStripe, off) / a.sampleCount, px, py);
                 printf("long block: pixel %d %d  cycles %lld  node steps %d leaf steps %d  max sp %d\n", px, py, tk2 - tk1, dbgNodes, dbgLeaves, dbgSp);
             }
             if (tk2 - tk1 > (1ll << 20)) st.bvh.diagB += tk2 - tk1 > (1ll << 24) ? (1u << 20) : (tk2 - tk1 > (1ll << 22) ? (1u << 10) : 1u);
@@ -1254,14 +1259,16 @@ __device__ __forceinline__ void shade_entry(const RenderArgs& a, const WfBufs& w
     o.seed = o.chk = 0u;
     o.ray.ox = o.ray.oy = o.ray.oz = o.ray.dx = o.ray.dy = o.ray.dz = o.ray.maxDist = 0.0f;
     o.acc.ox = o.acc.oy = o.acc.oz = o.acc.bx = o.acc.by = o.acc.bz = 0.0f;
-    o.slot = mine ? w.queue[pin] : kWfHole;
-    if (o.slot == kWfHole) return;
-    const uint2 hM = w.hitM[ph];
-    const uint32_t spp = a.sampleCount;
-    const uint32_t pix = o.slot / spp, sidx = o.slot - pix * spp;
+    o.slot = kWfHole;
+    if (!mine) return;
     const float4 d = w.rayD[pin];
+    if (level == 0 && wf_is_hole(d)) return;
+    const uint2 hM = w.hitM[ph];
     const float4 aO = level == 0 ? make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u)) : w.accO[pin];
     const float4 aB = level == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : w.accB[pin];
+    o.slot = level == 0 ? wf_level0_slot(stripe, off) : __float_as_uint(aB.w);
+    const uint32_t spp = a.sampleCount;
+    const uint32_t pix = o.slot / spp, sidx = o.slot - pix * spp;
     Ray ray; ray.ox = ray.oy = ray.oz = 0.0f; ray.maxDist = 0.0f; ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
     uint32_t seed = __float_as_uint(d.w), checksum = __float_as_uint(aO.w);
     PathAcc acc; acc.ox = aO.x; acc.oy = aO.y; acc.oz = aO.z; acc.bx = aB.x; acc.by = aB.y; acc.bz = aB.z;
@@ -1311,11 +1318,10 @@ __device__ __forceinline__ void shade_append(const WfBufs& w, const int level, c
     base = __shfl(base, 0);
     if (o.more) {
         const size_t po = wf_pos(w, level + 1, stripe, base + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull)));
-        w.queue[po] = o.slot;
         w.rayO[po] = make_float4(o.ray.ox, o.ray.oy, o.ray.oz, o.ray.maxDist);
         w.rayD[po] = make_float4(o.ray.dx, o.ray.dy, o.ray.dz, __uint_as_float(o.seed));
         w.accO[po] = make_float4(o.acc.ox, o.acc.oy, o.acc.oz, __uint_as_float(o.chk));
-        w.accB[po] = make_float4(o.acc.bx, o.acc.by, o.acc.bz, 0.0f);
+        w.accB[po] = make_float4(o.acc.bx, o.acc.by, o.acc.bz, __uint_as_float(o.slot));
     }
 }
 
@@ -1368,9 +1374,8 @@ __global__ __launch_bounds__(256, DEAL ? RT_SHADE_OCC : RT_SHADE_OCC + 1) void w
                 const uint32_t off = base + j * 256u + threadIdx.x;
                 const bool in = j < nbp && off < cnt;
                 const uint32_t g0 = in ? w.hitM[wf_hit_pos(w, stripe, off)].x : kWfMiss;
-                const uint32_t slot0 = in ? w.queue[wf_pos(w, level, stripe, off)] : kWfHole;
-                const bool isHit = slot0 != kWfHole && (g0 & kWfMiss) != kWfMiss;
-                const bool isMiss = slot0 != kWfHole && !isHit;
+                const bool isHit = in && (g0 & kWfMiss) != kWfMiss;   // no holes past the camera rays
+                const bool isMiss = in && !isHit;
                 cls |= (isHit ? 1u : (isMiss ? 2u : 0u)) << (2u * j);
                 const unsigned long long hb = __ballot(isHit), mb = __ballot(isMiss);
                 if (lane == 0) { runCnt[0][j * 4u + wave] = (uint32_t)__popcll(hb); runCnt[1][j * 4u + wave] = (uint32_t)__popcll(mb); }
