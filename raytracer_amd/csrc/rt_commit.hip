@@ -89,6 +89,7 @@ __global__ __launch_bounds__(256) void flatten_kernel(const Segment* __restrict_
         triRef[g] = ti;
 
         TriShade ts;
+        ts.pos = ti;
         float n[3][3] = { { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
         if (sg.nrm) {
 #pragma unroll

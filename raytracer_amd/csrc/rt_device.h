@@ -35,15 +35,18 @@ struct TriIsect {
 };
 static_assert(sizeof(TriIsect) == 48, "TriIsect layout");
 
-// 80 B, reference order: everything the winner needs besides its positions
-struct TriShade {
+// 128 B = one cache line, reference order: everything the shading of the winner needs -- a copy of its world-space
+// positions (48 B) in front of the 80 B of attributes, so that an incoherent hit costs one line instead of the
+// two to four that a 48-byte and an 80-byte record at unrelated addresses straddle
+struct __attribute__((aligned(128))) TriShade {
+    TriIsect pos;
     float n0[3], n1[3], n2[3];   // inverse-transpose transformed vertex normals (un-normalised)
     float uv0[2], uv1[2], uv2[2];
     uint32_t obj, mesh, tri;     // hit ids: object, mesh-in-object, triangle-in-mesh
     uint32_t matFlags;           // material id | hasNormals << 31
     uint32_t pad;
 };
-static_assert(sizeof(TriShade) == 80, "TriShade layout");
+static_assert(sizeof(TriShade) == 128, "TriShade layout");
 
 // 96 B per object: what intersectsObjectBoundingBox (GPURaytracer.cu:267-315) reads
 struct ObjCull {

@@ -167,9 +167,9 @@ struct Surface {
 __device__ __forceinline__ Surface shade_surface(const SceneView& s, const Hit& h, uint32_t& objOut, uint32_t& meshOut,
                                                  uint32_t& triOut, uint32_t matHint = kNoHit)
 {
-    const float4* tp = reinterpret_cast<const float4*>(s.triRef + h.gid);
+    const float4* tp = reinterpret_cast<const float4*>(s.triShade + h.gid); // one 128-byte line: positions, then attributes
     const float4 A = tp[0], B = tp[1], C = tp[2];
-    const float4* sp = reinterpret_cast<const float4*>(s.triShade + h.gid);
+    const float4* sp = tp + 3;
     const float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4];
     // TriShade: n0 = s0.xyz, n1 = (s0.w, s1.x, s1.y), n2 = (s1.z, s1.w, s2.x),
     //           uv0 = (s2.y, s2.z), uv1 = (s2.w, s3.x), uv2 = (s3.y, s3.z), obj = s3.w, mesh,tri,matFlags = s4.xyz
