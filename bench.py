@@ -66,6 +66,7 @@ class Job:
     """Shared state of one bench process: torch / RCCL, the context, its stream."""
 
     def __init__(self, args):
+        self.t0 = time.time()
         import torch
         import torch.distributed as dist
         from raytracer_amd import capi, multigpu
@@ -78,8 +79,11 @@ class Job:
         # RT_BENCH_REHEARSE=1: every rank on GPU 0 with gloo collectives -- a rehearsal of the N > 1 code paths on a one-GPU
         # box (RCCL refuses two ranks on one device); its timings mean nothing
         self.rehearse = bool(os.environ.get("RT_BENCH_REHEARSE"))
+        self.verbose = self.rehearse or bool(os.environ.get("RT_BENCH_VERBOSE"))
         if self.rehearse:
             self.local_rank = 0
+            import faulthandler
+            faulthandler.dump_traceback_later(int(os.environ.get("RT_BENCH_REHEARSE_LIMIT", "240")), exit=True)   # a hang names its line
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if self.rehearse:
@@ -110,10 +114,17 @@ class Job:
         self.torch.cuda.synchronize()
 
 
+def note(job, msg):
+    """Progress on stderr (RT_BENCH_VERBOSE=1 or the rehearsal): stdout carries the one JSON line only."""
+    if job.verbose:
+        print(f"[bench r{job.rank} {time.time() - job.t0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def measure(job, workload, mode, steps, warmup, cpu_baseline):
     """W untimed + K timed steps of one workload; returns the JSON object (rank 0) or None."""
     torch, dist, capi, multigpu, args, ctx = job.torch, job.dist, job.capi, job.multigpu, job.args, job.ctx
     rank, world, dev = job.rank, job.world, job.dev
+    note(job, f"{workload} / {mode}: building the scene")
     scene, cam, st, label = build_workload(workload, args)
     W, H = cam.width, cam.height
     flat = scene.flatten()
@@ -121,6 +132,7 @@ def measure(job, workload, mode, steps, warmup, cpu_baseline):
     ctx.upload_scene(flat)
     upload_s = time.time() - t0
     ctx.set_camera_rays(cam.preTransformRays)
+    note(job, f"{workload}: uploaded and committed in {upload_s:.1f} s")
 
     fa = tc = None
     if mode == "frames":
@@ -131,9 +143,10 @@ def measure(job, workload, mode, steps, warmup, cpu_baseline):
         fa = multigpu.FrameAccumulator(dist, world, rank, bufs, acc_t)
         frame_t = bufs[0]
     else:
-        tc = multigpu.TileCompositor(torch, dist, W, H, rank, world, dev)
-        fbs = [ctx.framebuffer_wrap(tc.frame.data_ptr(), W, H)]
-        frame_t = tc.frame
+        # two frames in flight: the all_gather of frame i runs on a side stream while frame i + 1 renders
+        tc = multigpu.TileCompositor(torch, dist, W, H, rank, world, dev, buffers=2 if world > 1 else 1)
+        fbs = [ctx.framebuffer_wrap(f.data_ptr(), W, H) for f in tc.frames]
+        frame_t = tc.frames[0]
 
     def step(frame_base):
         st.progressiveFrameCount = 0
@@ -145,19 +158,23 @@ def measure(job, workload, mode, steps, warmup, cpu_baseline):
         else:
             st.frameCount = frame_base
             if world > 1:
-                ctx.render(cam, st, fbs[0], bands=(multigpu.BAND_ROWS, rank, world))
-                tc.composite()
+                b = tc.acquire(frame_base)
+                ctx.render(cam, st, fbs[b], bands=(multigpu.BAND_ROWS, rank, world))
+                tc.submit(b)
             else:
                 ctx.render(cam, st, fbs[0])
 
     def barrier():
         if fa is not None:
             fa.drain()
+        if tc is not None:
+            tc.drain()
         job.barrier()
 
     for i in range(warmup):
         step(i)
     barrier()
+    note(job, f"{workload}: warm-up done")
     ctx.set_option(capi.OPT_ACCUMULATE_STATS, 1)
     barrier()
     ctx.event_record(0)
@@ -166,9 +183,12 @@ def measure(job, workload, mode, steps, warmup, cpu_baseline):
         step(warmup + i)
     if fa is not None:
         fa.drain()
+    if tc is not None:
+        tc.drain()
     ctx.event_record(1)
     barrier()
     elapsed = time.perf_counter() - t0
+    note(job, f"{workload}: {steps} steps in {elapsed:.3f} s")
     gpu_ms = ctx.event_elapsed_ms(0, 1)
     s = ctx.stats()
     rays_local = int(s.rays)
@@ -299,8 +319,8 @@ def main():
 
     job = Job(args)
     mode = args.mode or "frames"
-    out = measure(job, args.workload, mode, args.steps, args.warmup, cpu_baseline=not args.no_cpu_baseline and job.world == 1)
     custom = bool(args.width or args.height or args.spp or args.depth or args.brute)
+    out = measure(job, args.workload, mode, args.steps, args.warmup, cpu_baseline=not args.no_cpu_baseline and job.world == 1)
     if args.also and args.also != args.workload and not custom:
         # the north-star target config: one GPU renders the whole frame, N > 1 split it by image tiles
         also = measure(job, args.also, "tiles", args.steps, args.warmup, cpu_baseline=False)

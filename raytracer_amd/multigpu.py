@@ -54,30 +54,90 @@ class TileCompositor:
         unpack  one strided copy: gathered.permute(1, 0, ...) -> the padded frame
 
     No per-band Python loop, no allocation per frame.  Seeds use frame coordinates, so the composite is
-    bit-identical to the single-GPU frame."""
+    bit-identical to the single-GPU frame.
 
-    def __init__(self, torch, dist, width, height, rank, world, device=None, band_rows: int = BAND_ROWS, dtype=None):
-        self.dist, self.rank, self.world, self.band_rows = dist, rank, world, band_rows
+    `buffers` = 2 gives the pipelined form for a sequence of frames: frame i is rendered into buffer i % 2 and its
+    composite runs on a side stream (GPU) while frame i + 1 renders into the other buffer, the way FrameAccumulator
+    hides the reduce:
+
+        b = tc.acquire(i)        # buffer index for frame i, its previous composite finished (a stream dependency)
+        render(tc.frames[b])     # enqueue the rank's bands
+        tc.submit(b)             # pack + all_gather + unpack, behind the render, beside the next one
+        ...
+        tc.drain()               # everything finished; tc.frames[b] hold complete frames
+    """
+
+    def __init__(self, torch, dist, width, height, rank, world, device=None, band_rows: int = BAND_ROWS, dtype=None, buffers: int = 1,
+                 exchange=None):
+        """exchange: run the pack / all_gather / unpack even with one rank (default: only when world > 1).  A one-rank RCCL group
+        makes the same calls on the same streams as N ranks do, which is how the GPU tests reach this code on a one-GPU box."""
+        self.torch, self.dist, self.rank, self.world, self.band_rows = torch, dist, rank, world, band_rows
+        self.exchange = world > 1 if exchange is None else bool(exchange)
         self.width, self.height = width, height
         self.nb, self.per_rank, rows = band_layout(height, world, band_rows)
         dtype = dtype or torch.float32
-        self.padded = torch.zeros((rows, width, 4), dtype=dtype, device=device)
-        self.frame = self.padded[:height]
-        self.view = self.padded.view(self.per_rank, world, band_rows, width, 4)
-        self.packet = torch.empty((self.per_rank, band_rows, width, 4), dtype=dtype, device=device)
-        self.gathered = torch.empty((world, self.per_rank, band_rows, width, 4), dtype=dtype, device=device)
+        self.padded = [torch.zeros((rows, width, 4), dtype=dtype, device=device) for _ in range(buffers)]
+        self.frames = [p[:height] for p in self.padded]
+        self.views = [p.view(self.per_rank, world, band_rows, width, 4) for p in self.padded]
+        self.packets = [torch.empty((self.per_rank, band_rows, width, 4), dtype=dtype, device=device) for _ in range(buffers)]
+        self.gathered = [torch.empty((world, self.per_rank, band_rows, width, 4), dtype=dtype, device=device) for _ in range(buffers)]
+        self.frame, self.view = self.frames[0], self.views[0]
+        self.on_gpu = device is not None and torch.device(device).type == "cuda"
+        # the side stream is for RCCL, whose collectives are stream-ordered.  gloo's own device-tensor path stalls for seconds
+        # at a time on the GPU box when called off the default stream (tools/rehearse_probe.py), so under gloo (bench.py's
+        # one-GPU rehearsal) the packet is staged through pinned host memory here, in line
+        self.host = None
+        self.side = torch.cuda.Stream(device=device) if self.on_gpu and buffers > 1 and self.exchange and dist.get_backend() == "nccl" else None
+        self.done = [None] * buffers      # per buffer: event recorded on the side stream after the unpack
 
-    def composite(self):
-        """All ranks call this after rendering their bands into `frame`; on return `frame` is complete."""
-        if self.world == 1:
-            return self.frame
-        self.packet.copy_(self.view[:, self.rank])
+    def _composite(self, b):
+        self.packets[b].copy_(self.views[b][:, self.rank])
         if self.dist.get_backend() == "nccl":   # RCCL: straight into the contiguous [world, ...] tensor
-            self.dist.all_gather_into_tensor(self.gathered, self.packet)
+            self.dist.all_gather_into_tensor(self.gathered[b], self.packets[b])
+        elif self.on_gpu:                       # gloo under device tensors: staged through pinned host memory by hand
+            if self.host is None:
+                self.host = (self.packets[b].cpu().pin_memory(), self.gathered[b].cpu().pin_memory())
+            self.host[0].copy_(self.packets[b])
+            self.dist.all_gather(list(self.host[1].unbind(0)), self.host[0])
+            self.gathered[b].copy_(self.host[1])
         else:
-            self.dist.all_gather(list(self.gathered.unbind(0)), self.packet)
-        self.view.copy_(self.gathered.permute(1, 0, 2, 3, 4))
-        return self.frame
+            self.dist.all_gather(list(self.gathered[b].unbind(0)), self.packets[b])
+        self.views[b].copy_(self.gathered[b].permute(1, 0, 2, 3, 4))
+
+    def composite(self, b: int = 0):
+        """All ranks call this after rendering their bands into frames[b]; on return (in stream order) it is complete."""
+        if self.exchange:
+            self._composite(b)
+        return self.frames[b]
+
+    def acquire(self, i: int) -> int:
+        b = i % len(self.frames)
+        if self.done[b] is not None:
+            self.torch.cuda.current_stream().wait_event(self.done[b])
+            self.done[b] = None
+        return b
+
+    def submit(self, b: int):
+        if not self.exchange:
+            return
+        if self.side is None:
+            self._composite(b)
+            return
+        torch = self.torch
+        rendered = torch.cuda.Event()
+        rendered.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(rendered)
+            self._composite(b)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+        self.done[b] = ev
+
+    def drain(self):
+        for b in range(len(self.frames)):
+            if self.done[b] is not None:
+                self.torch.cuda.current_stream().wait_event(self.done[b])
+                self.done[b] = None
 
 
 def composite_tiles(dist, local_fb, width, height, rank, world, band_rows: int = BAND_ROWS):
@@ -111,11 +171,14 @@ class FrameAccumulator:
         fa.drain()               # all reduces finished, acc complete on dst
     """
 
-    def __init__(self, dist, world, rank, buffers, acc, dst=0):
+    def __init__(self, dist, world, rank, buffers, acc, dst=0, exchange=None):
+        """exchange: launch the reduce even with one rank (default: only when world > 1); see TileCompositor."""
         assert len(buffers) == 2
         self.dist, self.world, self.rank, self.buffers, self.acc, self.dst = dist, world, rank, buffers, acc, dst
+        self.exchange = world > 1 if exchange is None else bool(exchange)
         self.pending = [None, None]
         self.dirty = [False, False]
+        self.host = None
 
     def _finish(self, b):
         if self.pending[b] is not None:
@@ -132,8 +195,19 @@ class FrameAccumulator:
         return b
 
     def submit(self, b):
-        if self.world > 1:
-            self.pending[b] = self.dist.reduce(self.buffers[b], dst=self.dst, op=self.dist.ReduceOp.SUM, async_op=True)
+        if self.exchange:
+            buf = self.buffers[b]
+            if buf.is_cuda and self.dist.get_backend() != "nccl":
+                # gloo under device tensors (bench.py's one-GPU rehearsal): staged through pinned host memory by hand, in line;
+                # gloo's own device-tensor path stalls for seconds at a time off the default stream (tools/rehearse_probe.py)
+                if self.host is None:
+                    self.host = buf.cpu().pin_memory()
+                self.host.copy_(buf)
+                self.dist.reduce(self.host, dst=self.dst, op=self.dist.ReduceOp.SUM)
+                if self.rank == self.dst:
+                    buf.copy_(self.host)
+            else:   # RCCL (stream-ordered) or gloo on host tensors: in flight while the next frame renders
+                self.pending[b] = self.dist.reduce(buf, dst=self.dst, op=self.dist.ReduceOp.SUM, async_op=True)
         self.dirty[b] = True
 
     def drain(self):

@@ -149,10 +149,27 @@ comp2 = multigpu.composite_tiles(dist, torch.from_numpy(fb2[:44].copy()), 64, 44
 assert np.array_equal(comp2, full[:44]), "ragged tile composite differs"
 # the compositor bench.py uses: the frame lives in a padded tensor, one strided copy each way, no per-band loop
 tc = multigpu.TileCompositor(torch, dist, 64, 44, rank, world, band_rows=8)
-assert tc.padded.shape[0] == 48 and tc.frame.shape[0] == 44 and tc.per_rank == 3
+assert tc.padded[0].shape[0] == 48 and tc.frame.shape[0] == 44 and tc.per_rank == 3
 for b in range(rank, tc.nb, world):   # what rt_render_bands(firstBand = rank, bandStride = world) fills
     tc.frame[b * 8:min(44, (b + 1) * 8)] = torch.from_numpy(full[b * 8:min(44, (b + 1) * 8)])
 assert np.array_equal(tc.composite().numpy(), full[:44]), "TileCompositor differs"
+# ... and its pipelined form: two buffers, frame i composited while frame i + 1 is rendered (on CPU: in call order)
+tc2 = multigpu.TileCompositor(torch, dist, 64, 44, rank, world, band_rows=8, buffers=2)
+frames_ref = []
+for i in range(3):
+    st.frameCount = 10 + i
+    ref_i, _, _ = orc.render(flat, cam, st, threads=1)
+    frames_ref.append(ref_i)
+    b = tc2.acquire(i)
+    tc2.frames[b].zero_()
+    for band in range(rank, tc2.nb, world):
+        tc2.frames[b][band * 8:min(44, (band + 1) * 8)] = torch.from_numpy(ref_i[band * 8:min(44, (band + 1) * 8)])
+    tc2.submit(b)
+    if i >= 1:   # the previous frame's buffer is complete by now
+        assert np.array_equal(tc2.frames[(i - 1) % 2].numpy(), frames_ref[i - 1][:44])
+tc2.drain()
+assert np.array_equal(tc2.frames[0].numpy(), frames_ref[2][:44])
+st.frameCount = 0
 # frames: progressive split + reduce == serial sum within 1e-6
 frames = list(range(0, 6))
 local = torch.zeros((48, 64, 4))
