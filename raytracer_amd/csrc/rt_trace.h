@@ -85,19 +85,23 @@ __device__ __forceinline__ bool tri_test_core(const TriRay& q, float maxDist, fl
         e2 = (float)(b - a);
     }
 
-    if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) return false;
+    // The reference leaves after each of these tests (:600-625).  Here they are evaluated together and the lane leaves once:
+    // in a wave some lane nearly always goes on, so the separate exits only cost their own mask bookkeeping (a fifth of
+    // the instructions of a triangle step in wf_trace).  Same comparisons on the same operands, so the same decisions.
+    const bool mixed = (e0 < 0 || e1 < 0 || e2 < 0) & (e0 > 0 || e1 > 0 || e2 > 0);
     const float det = e0 + e1 + e2;
-    if (det == 0) return false;
 
     p0z *= q.sz; p1z *= q.sz; p2z *= q.sz;
     const float tScaled = e0 * p0z + e1 * p1z + e2 * p2z;
-    if (det < 0 && (tScaled >= 0 || tScaled < maxDist * det)) return false;
-    else if (det > 0 && (tScaled <= 0 || tScaled > maxDist * det)) return false;
+    const float md = maxDist * det;
+    const bool rejNeg = (det < 0) & ((tScaled >= 0) | (tScaled < md));
+    const bool rejPos = (det > 0) & ((tScaled <= 0) | (tScaled > md));
+    if (mixed | (det == 0) | rejNeg | rejPos) return false;
 
     const float invDet = 1 / det;
     const float t = tScaled * invDet;
-    if ((double)t < 0.001 || t > maxDist) return false;
-    if (!(t < FLT_MAX)) return false; // reference: a FLT_MAX / NaN distance never wins '<' (:421)
+    // (double)t < 0.001, t > maxDist, and the reference's '<' against FLT_MAX that a FLT_MAX / NaN distance never wins (:421)
+    if (((double)t < 0.001) | (t > maxDist) | !(t < FLT_MAX)) return false;
 
     tOut = t; b0Out = e0 * invDet; b1Out = e1 * invDet; b2Out = e2 * invDet;
     if (tsOut) *tsOut = tScaled;
@@ -251,7 +255,8 @@ __device__ __forceinline__ BoxRay make_box_ray(const Ray& r, float sceneMaxAbs)
     const float ddx = __builtin_fabsf(r.dx) < kTiny ? __builtin_copysignf(kTiny, r.dx) : r.dx;
     const float ddy = __builtin_fabsf(r.dy) < kTiny ? __builtin_copysignf(kTiny, r.dy) : r.dy;
     const float ddz = __builtin_fabsf(r.dz) < kTiny ? __builtin_copysignf(kTiny, r.dz) : r.dz;
-    b.ix = 1.0f / ddx; b.iy = 1.0f / ddy; b.iz = 1.0f / ddz;
+    // v_rcp_f32 (1 ulp): the box test only has to be conservative, and an ulp of a plane distance is far inside the pad
+    b.ix = __builtin_amdgcn_rcpf(ddx); b.iy = __builtin_amdgcn_rcpf(ddy); b.iz = __builtin_amdgcn_rcpf(ddz);
     b.sx = __builtin_signbit(r.dx); b.sy = __builtin_signbit(r.dy); b.sz = __builtin_signbit(r.dz);
     b.cnx = -((b.sx ? r.ox - pad : r.ox + pad) * b.ix);  b.cfx = -((b.sx ? r.ox + pad : r.ox - pad) * b.ix);
     b.cny = -((b.sy ? r.oy - pad : r.oy + pad) * b.iy);  b.cfy = -((b.sy ? r.oy + pad : r.oy - pad) * b.iy);
@@ -707,16 +712,16 @@ __device__ __forceinline__ void trav_test_triangle(Trav& T, const float4& A, con
 {
     float t, b0, b1, b2;
     if (tri_test_rot(T.q, T.m0, A, B, C, t, b0, b1, b2) && t <= T.bound) {
+        // selects, not branches: the lanes that get here differ in which of these apply
         const uint32_t gid = __float_as_uint(A.w), obj = __float_as_uint(B.w);
-        const bool better = t < T.best.t || (t == T.best.t && gid < T.best.gid);
-        if (obj != T.bestObj) {
-            if (better) { if (T.best.gid != kNoHit) T.otherT = T.best.t; T.bestObj = obj; }
-            else T.otherT = __builtin_fminf(T.otherT, t);
-        }
-        if (better) {
-            T.best.t = t; T.best.b0 = b0; T.best.b1 = b1; T.best.b2 = b2; T.best.gid = gid;
-            T.bound = __builtin_fminf(T.m0, t + band_of(t, T.rayScale, bandRel));
-        }
+        const bool better = (t < T.best.t) | ((t == T.best.t) & (gid < T.best.gid));
+        const bool other = obj != T.bestObj;
+        const float displaced = T.best.gid != kNoHit ? T.best.t : T.otherT;   // the hit a better one on another object pushes out
+        T.otherT = other ? (better ? displaced : __builtin_fminf(T.otherT, t)) : T.otherT;
+        T.bestObj = better ? obj : T.bestObj;
+        T.best.t = better ? t : T.best.t; T.best.b0 = better ? b0 : T.best.b0; T.best.b1 = better ? b1 : T.best.b1;
+        T.best.b2 = better ? b2 : T.best.b2; T.best.gid = better ? gid : T.best.gid;
+        T.bound = better ? __builtin_fminf(T.m0, t + band_of(t, T.rayScale, bandRel)) : T.bound;
     }
 }
 
