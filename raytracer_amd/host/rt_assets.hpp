@@ -330,11 +330,17 @@ inline bool loadObj(const std::string& path, FlatAsset& a)
         FlatMesh fm; fm.name = g.mat; fm.material = materialIndex(a, g.mat);
         bool allT = !vt.empty(), allN = !vn.empty();
         for (auto& p : g.polys) for (auto& c : p) { if (c.t < 0) allT = false; if (c.n < 0) allN = false; }
+        // an index past the arrays: the file is refused (assimp: "vertex index out of range"; the Python mirror raises)
+        for (auto& p : g.polys) for (auto& c : p) {
+            if (c.v < 0 || (size_t)c.v * 3 + 2 >= v.size()) return false;
+            if (allT && (size_t)c.t * 2 + 1 >= vt.size()) return false;
+            if (allN && (size_t)c.n * 3 + 2 >= vn.size()) return false;
+        }
         std::vector<int> counts;
         for (auto& p : g.polys) {
             counts.push_back((int)p.size());
             for (auto& c : p) {
-                for (int q = 0; q < 3; q++) fm.positions.push_back((size_t)c.v * 3 + q < v.size() && c.v >= 0 ? (float)v[c.v * 3 + q] : 0.0f);
+                for (int q = 0; q < 3; q++) fm.positions.push_back((float)v[c.v * 3 + q]);
                 if (allT) { fm.uvs.push_back((float)vt[c.t * 2]); fm.uvs.push_back((float)(1.0 - vt[c.t * 2 + 1])); } else { fm.uvs.push_back(0.0f); fm.uvs.push_back(0.0f); }
                 if (allN) for (int q = 0; q < 3; q++) fm.normals.push_back((float)vn[c.n * 3 + q]);
             }

@@ -90,20 +90,34 @@ struct Component {
 
 inline uint8_t clamp8(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
 
+// Two's-complement int that wraps: a corrupt stream can hold coefficients that overflow the transform's 32-bit intermediates.
+// stb_image computes in plain int there (wraps on every target it runs on); this type does the same without the undefined
+// behaviour, so a damaged file decodes to the same garbage instead of whatever the optimiser makes of an overflow.
+struct wint {
+    uint32_t u;
+    wint() : u(0) {}
+    wint(int v) : u((uint32_t)v) {}
+    int s() const { int v; memcpy(&v, &u, 4); return v; }
+    friend wint operator+(wint a, wint b) { wint r; r.u = a.u + b.u; return r; }
+    friend wint operator-(wint a, wint b) { wint r; r.u = a.u - b.u; return r; }
+    friend wint operator*(wint a, wint b) { wint r; r.u = a.u * b.u; return r; }
+    int operator>>(int k) const { return s() >> k; }   // arithmetic shift
+};
+
 // One pass of the LLM transform on eight values; C(x) = round(x * 4096).  even part in x0..x3, odd part in t0..t3.
-struct Llm { int x0, x1, x2, x3, t0, t1, t2, t3; };
-inline Llm llm_1d(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7)
+struct Llm { wint x0, x1, x2, x3, t0, t1, t2, t3; };
+inline Llm llm_1d(wint s0, wint s1, wint s2, wint s3, wint s4, wint s5, wint s6, wint s7)
 {
-    constexpr int C0_541 = 2217, Cm1_847 = -7567, C0_765 = 3135, C1_175 = 4816, C0_298 = 1223, C2_053 = 8410, C3_072 = 12586,
-                  C1_501 = 6149, Cm0_899 = -3685, Cm2_562 = -10497, Cm1_961 = -8034, Cm0_390 = -1597;
+    const wint C0_541 = 2217, Cm1_847 = -7567, C0_765 = 3135, C1_175 = 4816, C0_298 = 1223, C2_053 = 8410, C3_072 = 12586,
+               C1_501 = 6149, Cm0_899 = -3685, Cm2_562 = -10497, Cm1_961 = -8034, Cm0_390 = -1597, k4096 = 4096;
     Llm r;
-    const int z = (s2 + s6) * C0_541;
-    const int e2 = z + s6 * Cm1_847, e3 = z + s2 * C0_765;
-    const int e0 = (s0 + s4) * 4096, e1 = (s0 - s4) * 4096;
+    const wint z = (s2 + s6) * C0_541;
+    const wint e2 = z + s6 * Cm1_847, e3 = z + s2 * C0_765;
+    const wint e0 = (s0 + s4) * k4096, e1 = (s0 - s4) * k4096;
     r.x0 = e0 + e3; r.x3 = e0 - e3; r.x1 = e1 + e2; r.x2 = e1 - e2;
-    const int a = s7 + s3, b = s5 + s1, c = s7 + s1, d = s5 + s3;
-    const int z5 = (a + b) * C1_175;
-    const int pc = z5 + c * Cm0_899, pd = z5 + d * Cm2_562, pa = a * Cm1_961, pb = b * Cm0_390;
+    const wint a = s7 + s3, b = s5 + s1, c = s7 + s1, d = s5 + s3;
+    const wint z5 = (a + b) * C1_175;
+    const wint pc = z5 + c * Cm0_899, pd = z5 + d * Cm2_562, pa = a * Cm1_961, pb = b * Cm0_390;
     r.t3 = s1 * C1_501 + (pc + pb);
     r.t2 = s3 * C3_072 + (pd + pa);
     r.t1 = s5 * C2_053 + (pd + pb);
@@ -121,7 +135,8 @@ inline void idct8x8(uint8_t* out, int stride, const short d[64])
             continue;
         }
         Llm r = llm_1d(d[i], d[8 + i], d[16 + i], d[24 + i], d[32 + i], d[40 + i], d[48 + i], d[56 + i]);
-        r.x0 += 512; r.x1 += 512; r.x2 += 512; r.x3 += 512;
+        const wint bias = 512;
+        r.x0 = r.x0 + bias; r.x1 = r.x1 + bias; r.x2 = r.x2 + bias; r.x3 = r.x3 + bias;
         v[i] = (r.x0 + r.t3) >> 10; v[56 + i] = (r.x0 - r.t3) >> 10;
         v[8 + i] = (r.x1 + r.t2) >> 10; v[48 + i] = (r.x1 - r.t2) >> 10;
         v[16 + i] = (r.x2 + r.t1) >> 10; v[40 + i] = (r.x2 - r.t1) >> 10;
@@ -131,8 +146,8 @@ inline void idct8x8(uint8_t* out, int stride, const short d[64])
         const int* w = v + i * 8;
         uint8_t* o = out + (size_t)i * stride;
         Llm r = llm_1d(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
-        const int bias = 65536 + (128 << 17);
-        r.x0 += bias; r.x1 += bias; r.x2 += bias; r.x3 += bias;
+        const wint bias = 65536 + (128 << 17);
+        r.x0 = r.x0 + bias; r.x1 = r.x1 + bias; r.x2 = r.x2 + bias; r.x3 = r.x3 + bias;
         o[0] = clamp8((r.x0 + r.t3) >> 17); o[7] = clamp8((r.x0 - r.t3) >> 17);
         o[1] = clamp8((r.x1 + r.t2) >> 17); o[6] = clamp8((r.x1 - r.t2) >> 17);
         o[2] = clamp8((r.x2 + r.t1) >> 17); o[5] = clamp8((r.x2 - r.t1) >> 17);
@@ -251,6 +266,12 @@ inline bool decode_memory(const uint8_t* d, size_t size, std::vector<unsigned ch
             }
             for (auto& c : comp) if (hmax % c.h || vmax % c.v) return false;
             mcux = (width + hmax * 8 - 1) / (hmax * 8); mcuy = (height + vmax * 8 - 1) / (vmax * 8);
+            // A block costs at least two bits of entropy-coded data (an empty DC difference and an end-of-block), so a frame
+            // header that asks for more than four blocks per byte of file is damaged: refuse it before sizing buffers by it
+            // (a corrupt SOF can claim 65535 x 65535).  stb_image would allocate and decode such a file as far as it goes.
+            unsigned long long blocks = 0;
+            for (auto& c : comp) blocks += (unsigned long long)mcux * mcuy * c.h * c.v;
+            if (blocks > 4ull * size) return false;
             for (auto& c : comp) {
                 c.x = (width * c.h + hmax - 1) / hmax; c.y = (height * c.v + vmax - 1) / vmax;
                 c.w2 = mcux * c.h * 8; c.h2 = mcuy * c.v * 8;
@@ -282,8 +303,8 @@ inline bool decode_memory(const uint8_t* d, size_t size, std::vector<unsigned ch
                 memset(blk, 0, sizeof blk);
                 const int t = br.symbol(dc[c.td]);
                 if (t < 0 || t > 15) return false;
-                c.pred += t ? br.extend(t) : 0;
-                blk[0] = (short)(c.pred * q[0]);
+                c.pred = (wint(c.pred) + wint(t ? br.extend(t) : 0)).s();   // wraps on a corrupt stream, like the transform
+                blk[0] = (short)(wint(c.pred) * wint(q[0])).s();
                 for (int k = 1; k < 64;) {
                     const int rs = br.symbol(ac[c.ta]);
                     if (rs < 0) return false;

@@ -61,7 +61,7 @@ inline bool decode(const std::string& path, std::vector<unsigned char>& pix, int
         if (p + 12 + len > d.size()) return false;
         const std::string t((const char*)&d[p + 4], 4);
         const unsigned char* body = &d[p + 8];
-        if (t == "IHDR") { w = (int)rd32(p + 8); h = (int)rd32(p + 12); depth = body[8]; ctype = body[9]; interlace = body[12]; }
+        if (t == "IHDR") { if (len < 13) return false; w = (int)rd32(p + 8); h = (int)rd32(p + 12); depth = body[8]; ctype = body[9]; interlace = body[12]; }
         else if (t == "PLTE") plte.assign(body, body + len);
         else if (t == "IDAT") idat.insert(idat.end(), body, body + len);
         else if (t == "IEND") break;
@@ -71,7 +71,11 @@ inline bool decode(const std::string& path, std::vector<unsigned char>& pix, int
     const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!ch) return false;
     const int bpp = ch * depth / 8;
+    // stb_image's limit on either extent (STBI_MAX_DIMENSIONS); and deflate cannot expand by more than 1032 : 1, so a header
+    // that asks for more than the IDAT data can hold is damaged: refuse it before sizing buffers by it
+    if (w > (1 << 24) || h > (1 << 24)) return false;
     const size_t stride = (size_t)w * bpp;
+    if ((unsigned long long)(stride + 1) * (unsigned long long)h > 1032ull * idat.size() + 64ull) return false;
     std::vector<unsigned char> raw((stride + 1) * (size_t)h);
     uLongf rlen = (uLongf)raw.size();
     if (uncompress(raw.data(), &rlen, idat.data(), (uLong)idat.size()) != Z_OK || rlen != raw.size()) return false;
