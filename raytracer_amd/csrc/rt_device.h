@@ -120,7 +120,7 @@ struct SceneView {
 #define RT_EXACT_PASS 1   // 1: the tie-band rays of a level are listed and traced again by wf_exact before the level is shaded;
 #endif                    // 0: they flag their pixel for the redo launch instead (four launches per frame fewer, every flagged pixel's samples redone)
 #ifndef RT_EXACT_GRID
-#define RT_EXACT_GRID 128u
+#define RT_EXACT_GRID 256u
 #endif
 constexpr int kWfStripes = 64;
 constexpr int kWfCtrlStride = 32;          // words between two counters (one 128-byte line each)

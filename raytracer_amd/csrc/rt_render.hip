@@ -1198,7 +1198,14 @@ __global__ __launch_bounds__(256) void wf_exact_kernel(const RenderArgs a, const
     __syncthreads();
     const uint32_t n = listBase[kWfStripes];
     const size_t half = (size_t)(level & 1) * kWfStripes * (size_t)w.subCap;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    // The rays are few (1e-3 of a level on C4) and each walks on its own, so a wave runs as long as its slowest lane and
+    // mixes node and triangle phases on the way: they are spread over all the waves of the launch, `per` lanes of each.
+    const uint32_t waves = gridDim.x * 4u, wave = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    uint32_t per = (n + waves - 1u) / waves;
+    per = per < 1u ? 1u : (per > 64u ? 64u : per);
+    for (uint32_t base = wave * per; base < n; base += waves * per) {
+        const uint32_t i = base + lane;
+        if (lane >= per || i >= n) continue;
         uint32_t ls = 0;
 #pragma unroll
         for (uint32_t step = kWfStripes / 2; step > 0; step >>= 1)

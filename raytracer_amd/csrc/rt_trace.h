@@ -278,8 +278,10 @@ __device__ __forceinline__ f2 ubyte2_f(uint32_t v, int c) { return (f2){ (float)
 __device__ __forceinline__ f2 splat2(float v) { return (f2){ v, v }; }
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
+// tlo: distances below it are of no interest (0 in the hot kernels; the band walk of a ray whose closest hit is known
+// skips the boxes that end before it).
 __device__ __forceinline__ void node_test(const BoxRay& b, const float4& N0, const uint4& N1, const uint4& N2, float bound,
-                                          uint32_t key[4])
+                                          uint32_t key[4], const float tlo = 0.0f)
 {
     // N0 = ox oy oz sx | N1 = sy sz lox loy | N2 = loz hix hiy hiz
     const f2 ax = splat2(N0.w * b.ix), ay = splat2(__uint_as_float(N1.x) * b.iy), az = splat2(__uint_as_float(N1.y) * b.iz);
@@ -294,8 +296,8 @@ __device__ __forceinline__ void node_test(const BoxRay& b, const float4& N0, con
         const f2 t0x = pk_fma(ubyte2_f(qnx, c), ax, bnx), t1x = pk_fma(ubyte2_f(qfx, c), ax, bfx);
         const f2 t0y = pk_fma(ubyte2_f(qny, c), ay, bny), t1y = pk_fma(ubyte2_f(qfy, c), ay, bfy);
         const f2 t0z = pk_fma(ubyte2_f(qnz, c), az, bnz), t1z = pk_fma(ubyte2_f(qfz, c), az, bfz);
-        const float tn0 = __builtin_fmaxf(__builtin_fmaxf(t0x.x, t0y.x), __builtin_fmaxf(t0z.x, 0.0f));
-        const float tn1 = __builtin_fmaxf(__builtin_fmaxf(t0x.y, t0y.y), __builtin_fmaxf(t0z.y, 0.0f));
+        const float tn0 = __builtin_fmaxf(__builtin_fmaxf(t0x.x, t0y.x), __builtin_fmaxf(t0z.x, tlo));
+        const float tn1 = __builtin_fmaxf(__builtin_fmaxf(t0x.y, t0y.y), __builtin_fmaxf(t0z.y, tlo));
         const float tf0 = __builtin_fminf(__builtin_fminf(t1x.x, t1y.x), __builtin_fminf(t1z.x, bound));
         const float tf1 = __builtin_fminf(__builtin_fminf(t1x.y, t1y.y), __builtin_fminf(t1z.y, bound));
         key[c] = tn0 <= tf0 ? __float_as_uint(tn0) : kMissKey;
@@ -392,14 +394,14 @@ __device__ __forceinline__ void cmp_swap(uint32_t& ka, uint32_t& kb, int32_t& ia
 
 template <class STACK>
 __device__ __forceinline__ void node_step(const SceneView& s, const BoxRay& br, float bound, STACK& stack, int& sp,
-                                          int32_t& node)
+                                          int32_t& node, const float tlo = 0.0f)
 {
     const float4* np = reinterpret_cast<const float4*>(s.nodes + node);
     const float4 N0 = np[0];
     const uint4 N1 = reinterpret_cast<const uint4*>(np)[1], N2 = reinterpret_cast<const uint4*>(np)[2];
     const int4 CH = reinterpret_cast<const int4*>(np)[3];
     uint32_t k[4];
-    node_test(br, N0, N1, N2, bound, k);
+    node_test(br, N0, N1, N2, bound, k, tlo);
     int32_t c0 = CH.x, c1 = CH.y, c2 = CH.z, c3 = CH.w;
     const int h = (k[0] != kMissKey) + (k[1] != kMissKey) + (k[2] != kMissKey) + (k[3] != kMissKey);
     cmp_swap(k[0], k[1], c0, c1); cmp_swap(k[2], k[3], c2, c3);
@@ -412,7 +414,7 @@ __device__ __forceinline__ void node_step(const SceneView& s, const BoxRay& br, 
 
 template <class STACK, class Visit>
 __device__ __forceinline__ void bvh_walk(const SceneView& s, const BoxRay& br, const TriRay& q, float bound, STACK& stack,
-                                         BvhCounters& cnt, Visit&& visit)
+                                         BvhCounters& cnt, Visit&& visit, const float tlo = 0.0f)
 {
     if (!s.rootIsValid) return;
     int sp;
@@ -423,7 +425,7 @@ __device__ __forceinline__ void bvh_walk(const SceneView& s, const BoxRay& br, c
         while (node >= 0 && node != kTravEnd) {
             cnt.nodes++;
             count_idle(cnt.idleA);
-            node_step(s, br, bound, stack, sp, node);
+            node_step(s, br, bound, stack, sp, node, tlo);
             if (node < 0 && leaf == kTravEnd) { // park the first leaf, keep searching
                 leaf = node;
                 node = (int32_t)stack.pop(sp);
@@ -541,6 +543,10 @@ __device__ __forceinline__ bool trace_band_table(const SceneView& s, Ray& ray, f
                                            __builtin_fmaxf(__builtin_fabsf(ray.oz), s.sceneMaxAbs));
     const float m0 = ray.maxDist;
     const float limit = __builtin_fminf(tBest + band_of(tBest, rayScale, s.bandRel), m0);
+    // tBest is the closest accepted hit on any triangle, so the hits of interest lie in [tBest, limit]: boxes that end before
+    // tBest (less the band, for the slack of the box test) hold none of them.  Without this the walk visited everything the
+    // ray passes on its way to the hit, one dependent fetch after the other: the longest rays set the length of wf_exact.
+    const float tLow = __builtin_fmaxf(tBest - band_of(tBest, rayScale, s.bandRel), 0.0f);
     BandEntry e[kBandObjects];
 #pragma unroll
     for (int k = 0; k < kBandObjects; k++) {
@@ -571,7 +577,7 @@ __device__ __forceinline__ bool trace_band_table(const SceneView& s, Ray& ray, f
             if (!placed) ok = false;
         }
         return ok ? bound : -1.0f; // a bound below every entry distance: the walk only drains its stack
-    });
+    }, tLow);
     if (!ok) return false;
     // id order, empty entries (kNoHit) last: the reference's loop over the objects (:247-265)
 #pragma unroll
