@@ -1,0 +1,180 @@
+"""Random-scene soak of the HIP path against the CPU oracle: every seed draws a scene (object kinds, counts, scales over
+several decades, rotations, touching / duplicated / flat objects, materials with any subset of the maps, emitters), a
+camera, a frame size, sample count, depth, maxDistance, anti-aliasing, a progressive blend and a sub-rectangle, and the
+frame, the primary ids, the path checksum and the ray count must equal the oracle's bit for bit in the traversal modes.
+
+    python tests/soak_parity.py --first 0 --count 200        # on the GPU box; prints one line per seed, exits 1 on a mismatch
+
+tests/test_parity_gpu.py::test_random_scene_soak runs a fixed range of seeds with the suite."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import oracle_py as orc   # noqa: E402
+from raytracer_amd import capi, scenes   # noqa: E402
+from raytracer_amd.scene import Camera, Cube, Material, MeshObject, RenderSettings, Scene, Sphere, Texture   # noqa: E402
+
+
+def _quat(rng, mostly_axis=False):
+    if mostly_axis and rng.random() < 0.5:   # exact axis-aligned orientations: coplanar faces, axis-parallel edges
+        k = rng.integers(0, 4)
+        return [(0, 0, 0, 1), (0.70710678, 0, 0, 0.70710678), (0, 0.70710678, 0, 0.70710678), (0, 0, 1, 0)][k]
+    q = rng.normal(size=4)
+    return tuple(q / np.linalg.norm(q))
+
+
+def draw(seed):
+    """(scene, camera, settings, rect, prev) of a seed."""
+    rng = np.random.default_rng(1000 + seed)
+    style = seed % 6          # 0 ordinary, 1 decades of scale, 2 touching grid, 3 duplicates, 4 flat + tiny, 5 dense pile
+    n_obj = int(rng.integers(1, 40 if style != 5 else 90))
+    tex = int(rng.choice([32, 33, 64]))
+    mats = []
+    for k in range(int(rng.integers(1, 6))):
+        m = Material(f"m{k}", tuple(rng.random(3) * 0.9 + 0.05) + (1.0,), float(rng.random()), float(rng.random()),
+                     tuple(rng.random(3)), float(rng.random() * 3 * (rng.random() < 0.3)))
+        if rng.random() < 0.5:
+            m.setAlbedoTexture(Texture(scenes.procedural_texture(tex, seed + k, "albedo")))
+        if rng.random() < 0.4:
+            m.setNormalTexture(Texture(scenes.procedural_texture(tex, seed + 10 + k, "normal")))
+        if rng.random() < 0.4:
+            m.setRoughnessTexture(Texture(scenes.procedural_texture(32, seed + 20 + k, "scalar")[..., 0]))
+        if rng.random() < 0.4:
+            m.setMetalTexture(Texture(scenes.procedural_texture(tex, seed + 30 + k, "scalar")[..., :3]))
+        mats.append(m)
+    ell = scenes.merge_meshes([scenes.ellipsoid_mesh(0.5, 0.35, 0.45, int(rng.integers(4, 14)), int(rng.integers(3, 9)))])
+    box = scenes.merge_meshes([scenes.box_mesh((-0.4, -0.3, -0.5), (0.4, 0.3, 0.5))])
+    quad = scenes.merge_meshes([scenes.box_mesh((-0.5, 0.0, -0.5), (0.5, 0.0, 0.5))])   # zero thickness: the slab cull rejects it
+    sc = Scene()
+    extent = float(rng.choice([1.5, 4.0, 12.0]))
+    placed = []
+    for i in range(n_obj):
+        mat = mats[int(rng.integers(0, len(mats)))]
+        if style == 1:
+            scl = tuple(10.0 ** rng.uniform(-1.5, 1.2, 3))
+        elif style == 4 and rng.random() < 0.3:
+            scl = tuple(rng.uniform(0.01, 0.05, 3))
+        else:
+            scl = tuple(rng.uniform(0.4, 2.0, 3)) if rng.random() < 0.7 else (float(rng.uniform(0.4, 2.0)),) * 3
+        if style == 2:       # unit cells of a grid: faces of neighbours coincide exactly
+            pos = tuple(np.round(rng.uniform(-2, 2, 3)))
+            q, scl = (0, 0, 0, 1), (1.0, 1.0, 1.0)
+        elif style == 3 and placed and rng.random() < 0.4:   # the same object again, same place (or the same place, other scale)
+            pos, q, scl0 = placed[int(rng.integers(0, len(placed)))]
+            scl = scl0 if rng.random() < 0.6 else scl
+        elif style == 5:
+            pos, q = tuple(rng.normal(0, 0.6, 3)), _quat(rng)
+        else:
+            pos, q = tuple(rng.uniform(-extent, extent, 3) * (1, 0.5, 1)), _quat(rng, mostly_axis=True)
+        placed.append((pos, q, scl))
+        kind = int(rng.integers(0, 6)) if style != 2 else 1
+        if kind == 0:
+            o = Sphere(pos, q, scl); o.setMaterial(mat)
+        elif kind == 1:
+            o = Cube(); o.setPosition(pos); o.setRotation(q); o.setScale(scl); o.setMaterial(mat)
+        elif kind == 2:
+            o = MeshObject([(ell, 1), (box, 0)], [mat, mats[0]], pos, q, scl)
+        elif kind == 3:
+            o = MeshObject([(box, 0)], [mat], pos, q, scl)
+        elif kind == 4:
+            o = MeshObject([(ell, 0)], [mat], pos, q, scl)
+        else:
+            o = MeshObject([(quad, 0), (box, 0)] if rng.random() < 0.5 else [(quad, 0)], [mat], pos, q, scl)
+        sc.addToScene(f"o{i}", o)
+    if rng.random() < 0.5:   # a floor everything stands in
+        fl = MeshObject([(scenes.merge_meshes([scenes.box_mesh((-30, -1.0, -30), (30, -0.7, 30))]), 0)], [mats[0]])
+        sc.addToScene("floor", fl)
+    # camera: somewhere around, looking at a point near the middle
+    eye = rng.uniform(-1, 1, 3); eye = eye / np.linalg.norm(eye) * extent * rng.uniform(0.2, 3.0)
+    if style == 5 and rng.random() < 0.5:
+        eye = rng.normal(0, 0.2, 3)          # inside the pile
+    tgt = rng.normal(0, 0.3 * extent, 3)
+    f = tgt - eye; f /= np.linalg.norm(f)
+    # quaternion turning -z into f
+    z = np.array([0.0, 0.0, -1.0]); c = float(np.dot(z, f))
+    if c < -0.9999:
+        q = np.array([0.0, 1.0, 0.0, 0.0])
+    else:
+        ax = np.cross(z, f); q = np.array([ax[0], ax[1], ax[2], 1.0 + c]); q /= np.linalg.norm(q)
+    cam = Camera(tuple(eye.astype(np.float32)), tuple(q.astype(np.float32)), float(rng.uniform(25, 100)), float(rng.uniform(0.2, 3.0)))
+    W, H = int(rng.integers(9, 140)), int(rng.integers(9, 100))
+    cam.setWidth(W); cam.setHeight(H); cam.calcRays()
+    st = RenderSettings(bounceCount=int(rng.choice([0, 1, 2, 3, 4, 4, 5, 7])), sampleCount=int(rng.integers(1, 6)),
+                        antiAliasingEnabled=bool(rng.random() < 0.7), frameCount=int(rng.integers(0, 2 ** 31)),
+                        maxDistance=float(rng.choice([100.0, 100.0, 30.0, 6.0, 1.5])), aoIntensity=float(rng.choice([0.01, 0.0, 0.3])))
+    prev = None
+    if rng.random() < 0.3:
+        st.progressiveFrameCount = int(rng.integers(1, 9))
+        prev = rng.random((H, W, 4)).astype(np.float32)
+    rect = None
+    if rng.random() < 0.3:
+        x0, y0 = int(rng.integers(0, W - 4)), int(rng.integers(0, H - 4))
+        rect = (x0, y0, int(rng.integers(x0 + 1, W + 1)), int(rng.integers(y0 + 1, H + 1)))
+    return sc, cam, st, rect, prev
+
+
+def run_seed(ctx, seed, modes=(0, 2)):
+    """None when the seed passes, else a description of the first difference."""
+    sc, cam, st, rect, prev = draw(seed)
+    flat = sc.flatten()
+    ref, rid, nq = orc.render(flat, cam, st, rect=rect, prev=prev)
+    W, H = cam.width, cam.height
+    x0, y0, x1, y1 = rect or (0, 0, W, H)
+    for mode in modes:
+        ctx.set_option(capi.OPT_TRAVERSAL, mode)
+        ctx.upload_scene(flat)
+        ctx.set_camera_rays(cam.preTransformRays)
+        fb = ctx.framebuffer(W, H, ids=True)
+        if prev is not None:
+            ctx.write(fb, prev)
+        ctx.render(cam, st, fb, rect)
+        img, ids, rays = ctx.read(fb, W, H), ctx.read_ids(fb, W, H), ctx.stats().rays
+        ctx.framebuffer_destroy(fb)
+        inside = (slice(y0, y1), slice(x0, x1))
+        if prev is not None:   # outside the rectangle the previous frame stays
+            keep = np.ones((H, W), bool); keep[inside] = False
+            if not np.array_equal(img[keep], prev[keep]):
+                return f"mode {mode}: pixels outside the rectangle changed"
+        if not np.array_equal(ids[inside], rid[inside]):
+            bad = np.argwhere((ids[inside] != rid[inside]).any(-1))
+            return f"mode {mode}: ids differ at {len(bad)} pixels, first {tuple(bad[0] + (y0, x0))}"
+        if not np.array_equal(img[inside], ref[inside], equal_nan=True):
+            d = np.abs(img[inside].astype(np.float64) - ref[inside]); bad = np.argwhere(d.max(-1) > 0)
+            return f"mode {mode}: radiance differs at {len(bad)} pixels, max {d.max():.3g}, first {tuple(bad[0] + (y0, x0))}"
+        if rays != nq:
+            return f"mode {mode}: {rays} rays, oracle {nq}"
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--first", type=int, default=0)
+    ap.add_argument("--count", type=int, default=100)
+    ap.add_argument("--brute", action="store_true", help="also the reference-order brute-force mode")
+    a = ap.parse_args()
+    import torch
+    torch.cuda.is_available()      # torch's HIP runtime first (tests/conftest.py)
+    ctx = capi.Context(0)
+    failed = 0
+    t0 = time.time()
+    for seed in range(a.first, a.first + a.count):
+        why = run_seed(ctx, seed, (0, 2, 1) if a.brute else (0, 2))
+        sc, cam, st, rect, prev = draw(seed)
+        print(f"seed {seed:5d} {'ok  ' if why is None else 'FAIL'} {cam.width}x{cam.height} spp {st.sampleCount} "
+              f"depth {st.bounceCount} maxd {st.maxDistance:g} {'prog ' if prev is not None else ''}{'rect ' if rect else ''}"
+              f"{'' if why is None else why}  [{time.time() - t0:.0f} s]", flush=True)
+        failed += why is not None
+    ctx.close()
+    print(f"{a.count - failed} of {a.count} seeds equal the oracle bit for bit")
+    sys.exit(1 if failed else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -228,6 +228,21 @@ def test_render_bands_compose_the_frame(ctx, mode):
     ctx.framebuffer_destroy(fb); ctx.framebuffer_destroy(fb2)
 
 
+def test_framebuffer_write_right_after_create(ctx):
+    """rt_framebuffer_create clears the buffer in stream order: a write (or a render) that follows at once must not be
+    overtaken by the clear.  (It ran on the null stream once, which the context's non-blocking stream does not wait for:
+    2 of 28 000 random frames of tests/soak_parity.py lost a 4 KB page of their previous frame.)"""
+    rng = np.random.default_rng(9)
+    for w, h in ((123, 16), (82, 51), (640, 360), (31, 7)):
+        data = rng.random((h, w, 4)).astype(np.float32)
+        for _ in range(1500):
+            fb = ctx.framebuffer(w, h, ids=True)
+            ctx.write(fb, data)
+            got = ctx.read(fb, w, h)
+            ctx.framebuffer_destroy(fb)
+            assert np.array_equal(got, data)
+
+
 def test_present_and_screenshot(ctx, tmp_path):
     """rt_present: the RGBA32F texels the reference's window uploads for display (RenderWindow.cpp:172-176, 282-283) and the
     flipped sRGB8 screenshot (RenderWindow.cpp:389-421), converted on the GPU, byte for byte the host restatement --

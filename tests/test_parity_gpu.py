@@ -135,6 +135,15 @@ def test_textured_transformed_instances(ctx, spp, depth, aa):
     compare_modes(ctx, sc.flatten(), cam, st)
 
 
+def test_random_scene_soak(ctx):
+    """48 seeds of tests/soak_parity.py: random scenes, cameras, frame sizes, depths, maxDistance, progressive blends and
+    sub-rectangles, both BVH pipelines, bit for bit (the tool runs any range of seeds: 20 000 of them in all three modes were
+    clean once the framebuffer clear it caught racing with rt_framebuffer_write had been put in stream order)."""
+    import soak_parity
+    bad = {seed: why for seed in range(48) for why in [soak_parity.run_seed(ctx, seed)] if why}
+    assert not bad, bad
+
+
 def random_rays(rng, n, extent=4.0):
     o = rng.uniform(-extent * 2, extent * 2, (n, 3)).astype(np.float32)
     tgt = rng.uniform(-extent, extent, (n, 3)).astype(np.float32)
