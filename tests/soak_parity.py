@@ -127,6 +127,7 @@ def run_seed(ctx, seed, modes=(0, 2)):
     ref, rid, nq = orc.render(flat, cam, st, rect=rect, prev=prev)
     W, H = cam.width, cam.height
     x0, y0, x1, y1 = rect or (0, 0, W, H)
+    vr = np.random.default_rng(777 + seed)
     for mode in modes:
         ctx.set_option(capi.OPT_TRAVERSAL, mode)
         ctx.upload_scene(flat)
@@ -134,9 +135,25 @@ def run_seed(ctx, seed, modes=(0, 2)):
         fb = ctx.framebuffer(W, H, ids=True)
         if prev is not None:
             ctx.write(fb, prev)
-        ctx.render(cam, st, fb, rect)
-        img, ids, rays = ctx.read(fb, W, H), ctx.read_ids(fb, W, H), ctx.stats().rays
+        # the wavefront pipeline also through its other entry points and launch shapes, by the seed
+        how = ("plain", "noalloc", "bands", "chunks")[(seed // 6) % 4] if mode == 0 else "plain"
+        if how == "bands":
+            band_rows, world = int(vr.choice([8, 16, 64])), int(vr.integers(2, 6))
+            rays = 0
+            for r in range(world):
+                ctx.render(cam, st, fb, rect, bands=(band_rows, r, world))
+                rays += ctx.stats().rays
+        else:
+            if how == "chunks":
+                ctx.set_option(capi.OPT_WF_CHUNK, int(vr.choice([2048, 8192, 65536])))
+                ctx.set_option(capi.OPT_WF_LANES, int(vr.integers(0, 5)))
+            ctx.render(cam, st, fb, rect, noalloc=(how == "noalloc" and st.bounceCount <= 16))
+            rays = ctx.stats().rays
+            if how == "chunks":
+                ctx.set_option(capi.OPT_WF_CHUNK, 0); ctx.set_option(capi.OPT_WF_LANES, 0)
+        img, ids = ctx.read(fb, W, H), ctx.read_ids(fb, W, H)
         ctx.framebuffer_destroy(fb)
+        mode = f"{mode} ({how})"
         inside = (slice(y0, y1), slice(x0, x1))
         if prev is not None:   # outside the rectangle the previous frame stays
             keep = np.ones((H, W), bool); keep[inside] = False
