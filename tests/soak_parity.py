@@ -170,11 +170,79 @@ def run_seed(ctx, seed, modes=(0, 2)):
     return None
 
 
+def run_sequence(ctx, seed, steps=7):
+    """A live scene edited between frames, rendered through the GPURaytracer mirror (the reference's per-frame use: setters,
+    raytrace(), counters that advance): objects moved, rescaled, removed and added, material constants changed, maps bound,
+    swapped and cleared, the camera moved, progressive rendering switched on and off.  Every frame must equal the oracle's
+    for the scene as it stands.  None when the seed passes."""
+    import copy
+    rng = np.random.default_rng(5000 + seed)
+    sc, cam, st0, _, _ = draw(seed)
+    rt = capi.GPURaytracer(ctx)
+    ctx.set_option(capi.OPT_TRAVERSAL, 0)
+    rt.setBounceCount(min(st0.bounceCount, 5)); rt.setSampleCount(st0.sampleCount); rt.setMaxDistance(st0.maxDistance)
+    rt.setAntiAliasingEnabled(st0.antiAliasingEnabled); rt.setAOIntensity(st0.aoIntensity)
+    W, H = cam.width, cam.height
+    fb = ctx.framebuffer(W, H, ids=True)
+    prev = np.zeros((H, W, 4), np.float32)
+    extra = 0
+    try:
+        for step in range(steps):
+            objs = list(sc.getObjects().items())
+            for _ in range(int(rng.integers(0, 4))):
+                kind = int(rng.integers(0, 9))
+                if kind == 0 and objs:
+                    objs[int(rng.integers(0, len(objs)))][1].setPosition(tuple(rng.uniform(-3, 3, 3)))
+                elif kind == 1 and objs:
+                    objs[int(rng.integers(0, len(objs)))][1].setRotation(_quat(rng))
+                elif kind == 2 and objs:
+                    objs[int(rng.integers(0, len(objs)))][1].setScale(tuple(rng.uniform(0.3, 2.5, 3)))
+                elif kind == 3 and len(objs) > 1:
+                    sc.removeFromSceen(objs[int(rng.integers(0, len(objs)))][0])
+                elif kind == 4:
+                    o = Cube() if rng.random() < 0.5 else Sphere()
+                    o.setPosition(tuple(rng.uniform(-2, 2, 3))); o.setScale(tuple(rng.uniform(0.3, 1.5, 3)))
+                    o.setMaterial(Material(f"x{extra}", tuple(rng.random(3)) + (1.0,), float(rng.random()), float(rng.random())))
+                    sc.addToScene(f"extra{extra}", o); extra += 1
+                elif kind == 5 and objs:
+                    m = objs[int(rng.integers(0, len(objs)))][1].getMaterials()[0]
+                    m.simpleAlbedo = np.append(rng.random(3), 1.0).astype(np.float32); m.simpleRoughness = np.float32(rng.random())
+                    m.simpleMetal = np.float32(rng.random()); m.emissionStrength = np.float32(rng.random() * 2 * (rng.random() < 0.3))
+                elif kind == 6 and objs:
+                    m = objs[int(rng.integers(0, len(objs)))][1].getMaterials()[0]
+                    t = Texture(scenes.procedural_texture(32, int(rng.integers(0, 1000)), "albedo"))
+                    [m.setAlbedoTexture, m.setNormalTexture, m.setMetalTexture][int(rng.integers(0, 3))](t)
+                elif kind == 7 and objs:
+                    m = objs[int(rng.integers(0, len(objs)))][1].getMaterials()[0]
+                    [m.setAlbedoTexture, m.setNormalTexture, m.setRoughnessTexture, m.setMetalTexture][int(rng.integers(0, 4))](None)
+                else:
+                    cam.setPosition(cam.Position + rng.normal(0, 0.3, 3).astype(np.float32))
+                objs = list(sc.getObjects().items())
+            if rng.random() < 0.4:
+                rt.setProgressiveRendering(not rt.getProgressiveRendering())
+            st = copy.deepcopy(rt.st)          # the counters this frame renders with
+            flat = sc.flatten()
+            ref, rid, nq = orc.render(flat, cam, st, prev=prev if st.progressiveFrameCount > 0 else None)
+            rt.raytrace(sc, cam, fb)
+            img, ids, rays = ctx.read(fb, W, H), ctx.read_ids(fb, W, H), ctx.stats().rays
+            if not np.array_equal(ids, rid):
+                return f"step {step}: ids differ"
+            if not np.array_equal(img, ref, equal_nan=True):
+                return f"step {step}: radiance differs, max {np.abs(img.astype(np.float64) - ref).max():.3g}"
+            if rays != nq:
+                return f"step {step}: {rays} rays, oracle {nq}"
+            prev = img
+    finally:
+        ctx.framebuffer_destroy(fb)
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--count", type=int, default=100)
     ap.add_argument("--brute", action="store_true", help="also the reference-order brute-force mode")
+    ap.add_argument("--sequence", action="store_true", help="edited live scenes through the GPURaytracer mirror instead of single frames")
     a = ap.parse_args()
     import torch
     torch.cuda.is_available()      # torch's HIP runtime first (tests/conftest.py)
@@ -182,7 +250,7 @@ def main():
     failed = 0
     t0 = time.time()
     for seed in range(a.first, a.first + a.count):
-        why = run_seed(ctx, seed, (0, 2, 1) if a.brute else (0, 2))
+        why = run_sequence(ctx, seed) if a.sequence else run_seed(ctx, seed, (0, 2, 1) if a.brute else (0, 2))
         sc, cam, st, rect, prev = draw(seed)
         print(f"seed {seed:5d} {'ok  ' if why is None else 'FAIL'} {cam.width}x{cam.height} spp {st.sampleCount} "
               f"depth {st.bounceCount} maxd {st.maxDistance:g} {'prog ' if prev is not None else ''}{'rect ' if rect else ''}"

