@@ -292,7 +292,14 @@ __device__ __forceinline__ bool shade_segment(const RenderArgs& a, const Hit& h,
         const ObjCull o = load_obj(a.scene.objects + cullObj);
         float tmin, bfar;
         object_slab(ray, o, tmin, bfar);
-        if (!object_cull_pass(tmin, bfar, cullMax)) *cullFail = true;
+        // ... and a hit that lies before its object's box entry by more than the tie band (the object-space slab test of a
+        // ray that runs almost inside one of the box's planes can put the entry anywhere): the reference then drops the
+        // object as soon as an object earlier in the list has narrowed maxDistance below tmin, however far that hit is from
+        // this one (rt_trace.h, trace_bvh): the redo launch replays the whole object list for it.  Within the band the
+        // tie-band pass has already settled it (a triangle that lies in a face of its box has t = tmin up to rounding).
+        const float rayScale = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ray.ox), __builtin_fabsf(ray.oy)),
+                                               __builtin_fmaxf(__builtin_fabsf(ray.oz), a.scene.sceneMaxAbs));
+        if (!object_cull_pass(tmin, bfar, cullMax) || tmin > h.t + band_of(h.t, rayScale, a.scene.bandRel)) *cullFail = true;
     }
     const Surface sf = shade_surface(a.scene, h, ho, hm, ht, matHint);
     checksum += seg_hash(ho, hm, ht, sample, (uint32_t)i);

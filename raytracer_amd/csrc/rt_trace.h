@@ -474,6 +474,7 @@ __device__ __noinline__ Hit trace_bvh_exact(const SceneView& s, Ray& ray, const 
     const float m0 = ray.maxDist;
     float m = m0;
     uint32_t prev = kNoHit; // "no object yet"; object ids are < 2^31
+    bool widen = false;     // an object in the list whose box entry lies past the limit
     for (;;) {
         // next object id after `prev` that has an accepted hit within the limit
         uint32_t next = kNoHit;
@@ -484,12 +485,19 @@ __device__ __noinline__ Hit trace_bvh_exact(const SceneView& s, Ray& ray, const 
                 float t, b0, b1, b2;
                 if (tri_test_rot(q, m0, A, B, C, t, b0, b1, b2) && t <= limit) {
                     cull_lookup(s, ray, obj, cc);
-                    if (object_cull_pass(cc.tmin, cc.bfar, m0)) next = obj;
+                    if (object_cull_pass(cc.tmin, cc.bfar, m0)) { next = obj; if (cc.tmin > limit) widen = true; }
                 }
             }
             return bound;
         });
-        if (next == kNoHit) break;
+        if (next == kNoHit) {
+            // the list is done.  If one of its objects enters its box past the limit, objects past the limit can decide
+            // that object's cull: once more, over the whole list
+            if (!(widen && limit < m0)) break;
+            limit = m0; widen = false; prev = kNoHit; m = m0;
+            best.t = FLT_MAX; best.gid = kNoHit; best.b0 = best.b1 = best.b2 = 0.0f;
+            continue;
+        }
         prev = next;
         cull_lookup(s, ray, next, cc);
         if (!object_cull_pass(cc.tmin, cc.bfar, m)) continue;
@@ -535,7 +543,7 @@ struct BandEntry {
 constexpr int kBandObjects = 4;   // objects the table holds: a floor, the pile standing on it and two neighbours leaning into it
 
 __device__ __forceinline__ bool trace_band_table(const SceneView& s, Ray& ray, float tBest, Stack& stack, BvhCounters& cnt,
-                                                 Hit& out)
+                                                 Hit& out, bool* needAll = nullptr)
 {
     const TriRay q = make_tri_ray(ray);
     const BoxRay br = make_box_ray(ray, s.sceneMaxAbs);
@@ -554,7 +562,7 @@ __device__ __forceinline__ bool trace_band_table(const SceneView& s, Ray& ray, f
         e[k].h.t = FLT_MAX; e[k].h.gid = kNoHit; e[k].h.b0 = e[k].h.b1 = e[k].h.b2 = 0.0f;
         e[k].ts = e[k].det = 0.0f;
     }
-    bool ok = true;
+    bool ok = true, early = false;
     CullCache cc; cc.obj = kNoHit; cc.tmin = 0.0f; cc.bfar = 0.0f;
     bvh_walk(s, br, q, limit, stack, cnt, [&](const float4& A, const float4& B, const float4& C, float bound) {
         float t, b0, b1, b2, ts, det;
@@ -562,6 +570,7 @@ __device__ __forceinline__ bool trace_band_table(const SceneView& s, Ray& ray, f
         const uint32_t gid = __float_as_uint(A.w), obj = __float_as_uint(B.w);
         cull_lookup(s, ray, obj, cc);
         if (!object_cull_pass(cc.tmin, cc.bfar, m0)) ok = false;
+        else if (cc.tmin > limit) { ok = false; early = true; }   // its box entry lies past the band: only the whole object list settles it (trace_bvh)
         else {
             bool placed = false; // the entry of this object, or the first free one
 #pragma unroll
@@ -578,6 +587,7 @@ __device__ __forceinline__ bool trace_band_table(const SceneView& s, Ray& ray, f
         }
         return ok ? bound : -1.0f; // a bound below every entry distance: the walk only drains its stack
     }, tLow);
+    if (needAll) *needAll = early;
     if (!ok) return false;
     // id order, empty entries (kNoHit) last: the reference's loop over the objects (:247-265)
 #pragma unroll
@@ -619,6 +629,17 @@ __device__ __forceinline__ Hit trace_bvh(const SceneView& s, Ray& ray, Stack& st
     uint32_t bestObj = kNoHit;
     float otherT = FLT_MAX; // closest accepted hit on an object other than best's
     CullCache cc; cc.obj = kNoHit; cc.tmin = 0.0f; cc.bfar = 0.0f;
+    // In exact arithmetic a hit lies inside its object's box interval [tmin, far].  The reference's slab test runs in object
+    // space on a ray pushed through the host's float inverse, and for a ray that runs almost inside one of the box's planes
+    // (an axis-parallel ray against an object turned by 90 degrees, whose matrix holds 4e-8 where it means 0) the entry
+    // distance can land anywhere: tests/soak_parity.py found hits at t = 7.0 on objects whose box the ray "enters" at 7.42.
+    // Such an object passes its cull under the ray's own maxDistance and fails it as soon as ANY earlier object in the list
+    // has narrowed maxDistance below tmin (:252-262) -- a dependence on the object order that reaches as far as tmin, not
+    // just across the tie band.  So: a winner, or any of the band's candidates, whose box entry lies past the band sends the
+    // ray through the emulation of the whole object list (limit = the ray's maxDistance); inside the band the replay below
+    // evaluates every cull with the narrowed maxDistance anyway (a triangle that lies in a face of its box has t = tmin up
+    // to rounding: common, and harmless).  12 of 9 M soak rays.
+    float bestTmin = 0.0f;
 
     bvh_walk(s, br, q, m0, stack, cnt, [&](const float4& A, const float4& B, const float4& C, float bound) {
         float t, b0, b1, b2;
@@ -628,6 +649,7 @@ __device__ __forceinline__ Hit trace_bvh(const SceneView& s, Ray& ray, Stack& st
         cull_lookup(s, ray, obj, cc);
         if (!object_cull_pass(cc.tmin, cc.bfar, m0)) return bound;
         const bool better = t < best.t || (t == best.t && gid < best.gid);
+        if (better) bestTmin = cc.tmin;
         if (obj == bestObj) {
             if (better) { best.t = t; best.b0 = b0; best.b1 = b1; best.b2 = b2; best.gid = gid; }
         } else if (better) {
@@ -641,11 +663,13 @@ __device__ __forceinline__ Hit trace_bvh(const SceneView& s, Ray& ray, Stack& st
 
     if (best.gid == kNoHit) return best;
     const float limit = best.t + band_of(best.t, rayScale, s.bandRel);
-    if (otherT <= limit) { // first the one-walk replay on a two-object table, then the general emulation
+    if (bestTmin > limit) { slowPath++; return trace_bvh_exact(s, ray, q, br, m0, stack, cnt); }
+    if (otherT <= limit) { // first the one-walk replay on the object table, then the general emulation
         slowPath++;
         Hit out;
-        if (trace_band_table(s, ray, best.t, stack, cnt, out)) return out;
-        return trace_bvh_exact(s, ray, q, br, __builtin_fminf(limit, m0), stack, cnt);
+        bool needAll = false;
+        if (trace_band_table(s, ray, best.t, stack, cnt, out, &needAll)) return out;
+        return trace_bvh_exact(s, ray, q, br, needAll ? m0 : __builtin_fminf(limit, m0), stack, cnt);
     }
     ray.maxDist = best.t;
     return best;
@@ -810,7 +834,7 @@ __device__ __forceinline__ Hit trav_finish(Trav& T, const SceneView& s, Ray& ray
 {
     if (T.best.gid != kNoHit) {
         cull_lookup(s, ray, T.bestObj, T.cc);
-        if (!object_cull_pass(T.cc.tmin, T.cc.bfar, T.m0)) danger = true;
+        if (!object_cull_pass(T.cc.tmin, T.cc.bfar, T.m0) || T.cc.tmin > T.best.t + band_of(T.best.t, T.rayScale, s.bandRel)) danger = true;   // see trace_bvh on the second test
     }
     return trav_result(T, ray, danger, s.bandRel);
 }

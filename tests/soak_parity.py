@@ -167,6 +167,38 @@ def run_seed(ctx, seed, modes=(0, 2)):
             return f"mode {mode}: radiance differs at {len(bad)} pixels, max {d.max():.3g}, first {tuple(bad[0] + (y0, x0))}"
         if rays != nq:
             return f"mode {mode}: {rays} rays, oracle {nq}"
+    # rt_trace_rays on the same scene: rays between random points, rays aimed exactly at world-space vertices and edge
+    # midpoints, axis-parallel rays through them, several maxDistance values
+    n = 1500
+    verts = []
+    for o in flat.objects:
+        m = np.asarray(o["model"], np.float64).reshape(4, 4).T
+        for mid in o["meshIds"]:
+            v = flat.meshes[mid].vertices.reshape(-1, 3).astype(np.float64)
+            verts.append((v @ m[:3, :3].T + m[:3, 3]).astype(np.float32))
+    verts = np.concatenate(verts)
+    a, b = verts[vr.integers(0, len(verts), n)], verts[vr.integers(0, len(verts), n)]
+    tgt = np.where(vr.random((n, 1)) < 0.5, a, (0.5 * (a + b)).astype(np.float32))
+    tgt[: n // 3] = vr.uniform(-4, 4, (n // 3, 3))
+    org = vr.uniform(-9, 9, (n, 3)).astype(np.float32)
+    axis = vr.random(n) < 0.25
+    k = vr.integers(0, 3, n)
+    org[axis] = tgt[axis]
+    org[axis, k[axis]] += vr.choice([-7.0, 7.0], int(axis.sum())).astype(np.float32)
+    d = (tgt - org).astype(np.float32)
+    nz = np.linalg.norm(d, axis=1) > 0
+    d[nz] /= np.linalg.norm(d[nz], axis=1, keepdims=True)
+    d[~nz] = (0.0, 0.0, 1.0)
+    rays_q = np.zeros((n, 8), np.float32)
+    rays_q[:, :3] = org; rays_q[:, 3] = vr.choice([100.0, 100.0, 7.5, 3.0], n); rays_q[:, 4:7] = d
+    want = orc.trace_rays(flat, rays_q)
+    for tm in modes:
+        ctx.set_option(capi.OPT_TRAVERSAL, tm)
+        ctx.upload_scene(flat)
+        got = ctx.trace_rays(rays_q)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        if bad.size:
+            return f"trace_rays mode {tm}: {bad.size} of {n} rays differ, first {bad[0]}: {got[bad[0]]} vs {want[bad[0]]}"
     return None
 
 

@@ -137,10 +137,12 @@ def test_textured_transformed_instances(ctx, spp, depth, aa):
 
 def test_random_scene_soak(ctx):
     """48 seeds of tests/soak_parity.py: random scenes, cameras, frame sizes, depths, maxDistance, progressive blends and
-    sub-rectangles, both BVH pipelines, bit for bit (the tool runs any range of seeds: 20 000 of them in all three modes were
+    sub-rectangles, 1 500 ray queries each (random, aimed at vertices and edge midpoints, axis-parallel), all three modes, bit for bit (the tool runs any range of seeds: 20 000 of them in all three modes were
     clean once the framebuffer clear it caught racing with rt_framebuffer_write had been put in stream order)."""
     import soak_parity
-    bad = {seed: why for seed in range(48) for why in [soak_parity.run_seed(ctx, seed)] if why}
+    # ... and the seeds whose ray queries first showed hits lying before their object's box entry (rt_trace.h, trace_bvh)
+    early = [1365, 1833, 1911, 1941, 2011, 3237, 3862, 3924, 4443, 4599, 4731, 5917]
+    bad = {seed: why for seed in list(range(48)) + early for why in [soak_parity.run_seed(ctx, seed, (0, 2, 1))] if why}
     assert not bad, bad
 
 
