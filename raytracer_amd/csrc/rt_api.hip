@@ -240,6 +240,7 @@ rt::SceneView scene_view(const rt_ctx* c)
     s.rootIsValid = c->built.nTris > 0 ? 1 : 0;
     s.sceneMaxAbs = c->built.sceneMaxAbs;
     s.bandRel = c->bandRel;
+    s.thin = c->built.thin; s.nThin = c->built.nThin;
     return s;
 }
 

@@ -30,6 +30,8 @@ struct BuiltScene {
     uint32_t nTris = 0;
     uint32_t nNodes = 0;
     float sceneMaxAbs = 0.0f;
+    ThinTri* thin = nullptr;        // the (near) zero-area triangles, see thin_kernel
+    uint32_t nThin = 0, capThin = 0;
     // kept across commits (dynamic scenes re-commit every frame, Scene.cpp:3-29): the record arrays
     // while the triangle count fits, and one arena for every scratch array of the build
     uint32_t capTris = 0;

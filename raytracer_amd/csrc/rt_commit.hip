@@ -183,6 +183,45 @@ __global__ __launch_bounds__(256) void morton_kernel(const TriIsect* __restrict_
     vals[g] = g;
 }
 
+// Triangles of (nearly) no area.  The reference's watertight test decides by the signs of three edge functions computed in
+// binary32; when the ray passes within rounding of the LINE through a collinear triangle, all three are rounding noise and a
+// hit is reported a quarter of the time -- wherever along that line the triangle lies, at a "hit point" inside the triangle
+// and so possibly far from the ray.  No bounding box can stand for that: a BVH walk never gets near such a triangle
+// (tests/soak_parity.py: objects with two axes scaled to zero, rays aimed at their vertices: 6 of 18 M ray queries returned a
+// farther hit; the reference's own sword model holds ten such triangles).  An edge function is p_a x p_b with an error of
+// 2^-22 |p_a||p_b|, so a violated edge decides correctly unless it subtends less than 2^-22 rad at the crossing point; for a
+// triangle of altitude w seen from up to 2 S away (S = the scene's largest |coordinate|) that needs w < 2^-20 S.  Triangles
+// with altitude below 2^-17 S are listed here, as the line they lie on, and the walks of the exact paths (bvh_walk: every
+// rt_trace_rays query, the redo launches, wf_exact) test them after the tree, behind a cheap test of the ray's distance to that
+// line (rt_trace.h, thin_near).  The hot render kernels do NOT: for a camera or bounce ray to pass within ~1e-7 of such a line
+// does not happen -- 200 M rays of a C3 frame (tools/thin_check.py) are identical to the brute-force mode without any of
+// this -- and looking out for it in wf_shade cost C3 a fifth of its frame time.  RT_OPT_TRAVERSAL = 1 is there for a caller
+// who needs the guarantee on such a scene.  The triangles stay in the tree as well (testing one twice changes nothing).  A
+// triangle of no extent at all, or with a vertex that is not finite, is never hit (all three edge functions are exactly 0,
+// or NaN) and is not listed.
+__global__ __launch_bounds__(256) void thin_kernel(const TriIsect* __restrict__ triRef, uint32_t nTris, float tau,
+                                                   uint32_t* __restrict__ count, ThinTri* __restrict__ list)
+{
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nTris) return;
+    const TriIsect t = triRef[g];
+    const float ax = t.v1x - t.v0x, ay = t.v1y - t.v0y, az = t.v1z - t.v0z;   // v0 -> v1
+    const float bx = t.v2x - t.v0x, by = t.v2y - t.v0y, bz = t.v2z - t.v0z;   // v0 -> v2
+    const float cx = t.v2x - t.v1x, cy = t.v2y - t.v1y, cz = t.v2z - t.v1z;   // v1 -> v2
+    const float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+    const float area2 = sqrtf(nx * nx + ny * ny + nz * nz);
+    const float la = sqrtf(ax * ax + ay * ay + az * az), lb = sqrtf(bx * bx + by * by + bz * bz), lc = sqrtf(cx * cx + cy * cy + cz * cz);
+    const float longest = fmaxf(fmaxf(la, lb), lc);
+    if (!(longest > 0.0f) || !(longest < FLT_MAX)) return;
+    if (!(area2 / longest < tau)) return;
+    ThinTri r;
+    r.gid = g; r.k = 3.814697265625e-06f / longest; r.len2 = longest * longest; r.pad[0] = r.pad[1] = r.pad[2] = 0u;
+    if (lc >= la && lc >= lb) { r.px = t.v1x; r.py = t.v1y; r.pz = t.v1z; r.ux = cx / lc; r.uy = cy / lc; r.uz = cz / lc; }
+    else if (lb >= la) { r.px = t.v0x; r.py = t.v0y; r.pz = t.v0z; r.ux = bx / lb; r.uy = by / lb; r.uz = bz / lb; }
+    else { r.px = t.v0x; r.py = t.v0y; r.pz = t.v0z; r.ux = ax / la; r.uy = ay / la; r.uz = az / la; }
+    list[atomicAdd(count, 1u)] = r;
+}
+
 // boxes of the triangles in sorted (Morton) order: "node" N-1+j of the binary tree is sorted triangle j
 __global__ __launch_bounds__(256) void leafbox_kernel(const TriIsect* __restrict__ triRef, const uint32_t* __restrict__ order,
                                                       uint32_t nTris, float* __restrict__ boxes)
@@ -586,6 +625,7 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
     out.nTris = nTris;
     out.nNodes = 0;
     out.sceneMaxAbs = 0.0f;
+    out.nThin = 0;
     if (nTris == 0) return true;
     const uint32_t grid = (nTris + 255) / 256;
     const uint32_t nInternal = nTris > 1 ? nTris - 1 : 1;
@@ -603,7 +643,8 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
 
     // scratch: carved out of one arena that survives the commit (a re-commit of a scene of the same
     // size allocates nothing)
-    uint32_t *dBounds = nullptr, *valsA = nullptr, *valsB = nullptr, *done = nullptr, *remaining = nullptr;
+    uint32_t *dBounds = nullptr, *valsA = nullptr, *valsB = nullptr, *done = nullptr, *remaining = nullptr, *thinCount = nullptr;
+    ThinTri* thinTmp = nullptr;
     unsigned long long *keysA = nullptr, *keysB = nullptr;
     int2 *queueA = nullptr, *queueB = nullptr;
     float* boxes = nullptr;
@@ -629,7 +670,7 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
         const size_t oBounds = take(6 * sizeof(uint32_t)), oKeysA = take(8 * n), oKeysB = take(8 * n), oValsA = take(4 * n),
                      oValsB = take(4 * n), oSort = take(tmpBytes ? tmpBytes : 16), oBoxes = take(sizeof(float) * 6 * 2 * n),
                      oChildren = take(sizeof(int2) * ni), oCount = take(sizeof(int) * ni), oDone = take(4 * ni),
-                     oRemaining = take(4), oParent = take(sizeof(int) * (2 * n)), oQueueA = take(sizeof(int2) * ni), oQueueB = take(sizeof(int2) * ni);
+                     oRemaining = take(4), oThinCount = take(4), oThin = take(sizeof(ThinTri) * n), oParent = take(sizeof(int) * (2 * n)), oQueueA = take(sizeof(int2) * ni), oQueueB = take(sizeof(int2) * ni);
         if (off > out.arenaBytes) {
             hipFree(out.arena); out.arena = nullptr; out.arenaBytes = 0;
             RT_HIP(hipMalloc(&out.arena, off));
@@ -639,6 +680,7 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
         dBounds = (uint32_t*)(base + oBounds); keysA = (unsigned long long*)(base + oKeysA); keysB = (unsigned long long*)(base + oKeysB);
         valsA = (uint32_t*)(base + oValsA); valsB = (uint32_t*)(base + oValsB); sortTmp = base + oSort; boxes = (float*)(base + oBoxes);
         children = (int2*)(base + oChildren); count = (int*)(base + oCount); done = (uint32_t*)(base + oDone);
+        thinCount = (uint32_t*)(base + oThinCount); thinTmp = (ThinTri*)(base + oThin);
         remaining = (uint32_t*)(base + oRemaining); parent = (int*)(base + oParent); queueA = (int2*)(base + oQueueA); queueB = (int2*)(base + oQueueB);
     }
 
@@ -658,6 +700,23 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
         if (f < FLT_MAX && f > -FLT_MAX && fabsf(f) > maxAbs) maxAbs = fabsf(f);
     }
     out.sceneMaxAbs = maxAbs;
+
+    // the triangles no box can stand for (thin_kernel)
+    RT_HIPC(hipMemsetAsync(thinCount, 0, 4, stream));
+    hipLaunchKernelGGL(thin_kernel, dim3(grid), dim3(256), 0, stream, out.triRef, nTris, maxAbs * 7.62939453125e-06f, thinCount, thinTmp);
+    RT_HIPC(hipGetLastError());
+    {
+        uint32_t n = 0;
+        RT_HIPC(hipMemcpyAsync(&n, thinCount, 4, hipMemcpyDeviceToHost, stream));
+        RT_HIPC(hipStreamSynchronize(stream));
+        if (n > out.capThin) {
+            hipFree(out.thin); out.thin = nullptr; out.capThin = 0;
+            RT_HIP(hipMalloc((void**)&out.thin, sizeof(ThinTri) * (size_t)n));
+            out.capThin = n;
+        }
+        if (n) RT_HIPC(hipMemcpyAsync(out.thin, thinTmp, sizeof(ThinTri) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+        out.nThin = n;
+    }
 
     MortonPlan plan{ 0, 0 };
     {
@@ -807,7 +866,7 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
 
 void free_scene(BuiltScene& s)
 {
-    hipFree(s.triRef); hipFree(s.triLeaf); hipFree(s.triShade); hipFree(s.nodes); hipFree(s.arena);
+    hipFree(s.triRef); hipFree(s.triLeaf); hipFree(s.triShade); hipFree(s.nodes); hipFree(s.arena); hipFree(s.thin);
     s = BuiltScene();
 }
 

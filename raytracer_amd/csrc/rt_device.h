@@ -97,6 +97,15 @@ struct BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode layout");
 
+// A triangle of (nearly) no area, as the line it lies on: the end of its longest edge, the edge's unit direction, and the two
+// constants of the proximity test (rt_trace.h, thin_near): k = 2^-18 / length, len2 = length^2.
+struct ThinTri {
+    float px, py, pz, k;
+    float ux, uy, uz, len2;
+    uint32_t gid, pad[3];
+};
+static_assert(sizeof(ThinTri) == 48, "ThinTri layout");
+
 struct SceneView {
     const TriIsect* triRef;    // [nTris] reference order
     const TriIsect* triLeaf;   // [3][nTris] BVH leaf order; copy k holds the coordinates rotated for rays whose
@@ -110,6 +119,8 @@ struct SceneView {
     int32_t rootIsValid;       // 0 when the scene holds no triangle
     float sceneMaxAbs;         // max |coordinate| over all world-space vertices
     float bandRel;             // relative width of the tie band (rt_trace.h band_of): 2e-4, or wider for ill-conditioned instances
+    const ThinTri* thin;       // [nThin] the triangles no box can stand for (rt_commit.hip, thin_kernel)
+    uint32_t nThin;
 };
 
 // ---- wavefront pipeline (rt_render.hip, "wf_" kernels) ----

@@ -412,8 +412,28 @@ __device__ __forceinline__ void node_step(const SceneView& s, const BoxRay& br, 
     if (h == 0) node = (int32_t)stack.pop(sp);
 }
 
+// The triangles no box can stand for (SceneView::thin; rt_commit.hip, thin_kernel).  A ray can only "hit" one where all three
+// of its edges subtend less than ~2^-22 rad, i.e. within 2^-22 r^2 / len of the line it lies on, r the distance to it: the
+// test below (eight times that, squared) lets nearly every ray skip the triangle; the records are the same for every lane.
+__device__ __forceinline__ bool thin_near(const ThinTri& r, const Ray& ray)
+{
+    const float wx = r.px - ray.ox, wy = r.py - ray.oy, wz = r.pz - ray.oz;
+    const float nx = ray.dy * r.uz - ray.dz * r.uy, ny = ray.dz * r.ux - ray.dx * r.uz, nz = ray.dx * r.uy - ray.dy * r.ux;
+    const float num = wx * nx + wy * ny + wz * nz;                 // distance between the lines = |num| / |n|
+    const float n2 = nx * nx + ny * ny + nz * nz;
+    const float rad = r.k * (wx * wx + wy * wy + wz * wz + r.len2) + 1e-30f;   // >= 2^-19 (|w| + len)^2 / len, without the root
+    return !(num * num > rad * rad * n2);                          // parallel lines (n = 0) and NaN stay in
+}
+// ... as a leaf copy would hold it for a ray of dominant axis kz
+__device__ __forceinline__ void thin_record(const SceneView& s, uint32_t gid, int kz, float4& A, float4& B, float4& C)
+{
+    const TriIsect t = s.triRef[gid];
+    A = make_float4(sel3(kz, t.v0y, t.v0z, t.v0x), sel3(kz, t.v0z, t.v0x, t.v0y), sel3(kz, t.v0x, t.v0y, t.v0z), __uint_as_float(t.gid));
+    B = make_float4(sel3(kz, t.v1y, t.v1z, t.v1x), sel3(kz, t.v1z, t.v1x, t.v1y), sel3(kz, t.v1x, t.v1y, t.v1z), __uint_as_float(t.obj));
+    C = make_float4(sel3(kz, t.v2y, t.v2z, t.v2x), sel3(kz, t.v2z, t.v2x, t.v2y), sel3(kz, t.v2x, t.v2y, t.v2z), __uint_as_float(t.mat));
+}
 template <class STACK, class Visit>
-__device__ __forceinline__ void bvh_walk(const SceneView& s, const BoxRay& br, const TriRay& q, float bound, STACK& stack,
+__device__ __forceinline__ void bvh_walk(const SceneView& s, const Ray& ray, const BoxRay& br, const TriRay& q, float bound, STACK& stack,
                                          BvhCounters& cnt, Visit&& visit, const float tlo = 0.0f)
 {
     if (!s.rootIsValid) return;
@@ -449,6 +469,15 @@ __device__ __forceinline__ void bvh_walk(const SceneView& s, const BoxRay& br, c
             }
         }
     }
+    // the triangles no box can stand for (rt_commit.hip, thin_kernel): a handful at most in a sane scene, none in most
+    for (uint32_t k = 0; k < s.nThin; k++) {
+        const ThinTri r = s.thin[k];
+        if (!thin_near(r, ray)) continue;
+        float4 A, B, C;
+        thin_record(s, r.gid, q.kz, A, B, C);
+        cnt.tris++;
+        bound = visit(A, B, C, bound);
+    }
 }
 
 struct CullCache {
@@ -479,7 +508,7 @@ __device__ __noinline__ Hit trace_bvh_exact(const SceneView& s, Ray& ray, const 
         // next object id after `prev` that has an accepted hit within the limit
         uint32_t next = kNoHit;
         CullCache cc; cc.obj = kNoHit; cc.tmin = 0.0f; cc.bfar = 0.0f;
-        bvh_walk(s, br, q, limit, stack, cnt, [&](const float4& A, const float4& B, const float4& C, float bound) {
+        bvh_walk(s, ray, br, q, limit, stack, cnt, [&](const float4& A, const float4& B, const float4& C, float bound) {
             const uint32_t obj = __float_as_uint(B.w);
             if ((prev == kNoHit || obj > prev) && obj < next) {
                 float t, b0, b1, b2;
@@ -503,7 +532,7 @@ __device__ __noinline__ Hit trace_bvh_exact(const SceneView& s, Ray& ray, const 
         if (!object_cull_pass(cc.tmin, cc.bfar, m)) continue;
         // closest hit inside that object with ray.maxDistance = m
         Hit ob; ob.t = FLT_MAX; ob.gid = kNoHit; ob.b0 = ob.b1 = ob.b2 = 0.0f;
-        bvh_walk(s, br, q, m, stack, cnt, [&](const float4& A, const float4& B, const float4& C, float bound) {
+        bvh_walk(s, ray, br, q, m, stack, cnt, [&](const float4& A, const float4& B, const float4& C, float bound) {
             if (__float_as_uint(B.w) == next) {
                 float t, b0, b1, b2;
                 if (tri_test_rot(q, m, A, B, C, t, b0, b1, b2)) {
@@ -564,7 +593,7 @@ __device__ __forceinline__ bool trace_band_table(const SceneView& s, Ray& ray, f
     }
     bool ok = true, early = false;
     CullCache cc; cc.obj = kNoHit; cc.tmin = 0.0f; cc.bfar = 0.0f;
-    bvh_walk(s, br, q, limit, stack, cnt, [&](const float4& A, const float4& B, const float4& C, float bound) {
+    bvh_walk(s, ray, br, q, limit, stack, cnt, [&](const float4& A, const float4& B, const float4& C, float bound) {
         float t, b0, b1, b2, ts, det;
         if (!tri_test_rot(q, m0, A, B, C, t, b0, b1, b2, &ts, &det) || t > limit) return bound;
         const uint32_t gid = __float_as_uint(A.w), obj = __float_as_uint(B.w);
@@ -641,7 +670,7 @@ __device__ __forceinline__ Hit trace_bvh(const SceneView& s, Ray& ray, Stack& st
     // to rounding: common, and harmless).  12 of 9 M soak rays.
     float bestTmin = 0.0f;
 
-    bvh_walk(s, br, q, m0, stack, cnt, [&](const float4& A, const float4& B, const float4& C, float bound) {
+    bvh_walk(s, ray, br, q, m0, stack, cnt, [&](const float4& A, const float4& B, const float4& C, float bound) {
         float t, b0, b1, b2;
         if (!tri_test_rot(q, m0, A, B, C, t, b0, b1, b2)) return bound;
         if (t > bound) return bound;

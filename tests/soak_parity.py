@@ -33,7 +33,9 @@ def _quat(rng, mostly_axis=False):
 def draw(seed):
     """(scene, camera, settings, rect, prev) of a seed."""
     rng = np.random.default_rng(1000 + seed)
-    style = seed % 6          # 0 ordinary, 1 decades of scale, 2 touching grid, 3 duplicates, 4 flat + tiny, 5 dense pile
+    style = seed % 6 if seed < 100000 else seed % 8   # (seeds below 100 000 keep the six styles they were first run with)
+                              # 0 ordinary, 1 decades of scale, 2 touching grid, 3 duplicates, 4 flat + tiny, 5 dense pile,
+                              # 6 everything axis-aligned on a half-unit grid with an axis-aligned camera, 7 ordinary with a collapsed axis
     n_obj = int(rng.integers(1, 40 if style != 5 else 90))
     tex = int(rng.choice([32, 33, 64]))
     mats = []
@@ -71,8 +73,14 @@ def draw(seed):
             scl = scl0 if rng.random() < 0.6 else scl
         elif style == 5:
             pos, q = tuple(rng.normal(0, 0.6, 3)), _quat(rng)
+        elif style == 6:
+            pos = tuple(np.round(rng.uniform(-3, 3, 3) * 2) / 2)
+            q = [(0, 0, 0, 1), (0.70710678, 0, 0, 0.70710678), (0, 0.70710678, 0, 0.70710678), (0, 0, 0.70710678, 0.70710678), (0, 0, 1, 0), (1, 0, 0, 0)][int(rng.integers(0, 6))]
+            scl = tuple(rng.choice([0.5, 1.0, 1.0, 2.0], 3))
         else:
             pos, q = tuple(rng.uniform(-extent, extent, 3) * (1, 0.5, 1)), _quat(rng, mostly_axis=True)
+        if style == 7 and rng.random() < 0.15:     # one axis collapsed: a singular model matrix, a non-finite inverse
+            scl = tuple(0.0 if k == int(rng.integers(0, 3)) else v for k, v in enumerate(scl))
         placed.append((pos, q, scl))
         kind = int(rng.integers(0, 6)) if style != 2 else 1
         if kind == 0:
@@ -103,11 +111,18 @@ def draw(seed):
         q = np.array([0.0, 1.0, 0.0, 0.0])
     else:
         ax = np.cross(z, f); q = np.array([ax[0], ax[1], ax[2], 1.0 + c]); q /= np.linalg.norm(q)
+    if style == 6:   # on the grid, looking along an axis: the centre rays are axis-parallel and meet vertices, edges and faces exactly
+        eye = np.round(rng.uniform(-4, 4, 3) * 2) / 2
+        eye[int(rng.integers(0, 3))] = float(rng.choice([-8.0, 8.0, 6.5]))
+        q = np.array([(0, 0, 0, 1), (0, 1, 0, 0), (0, 0.70710678, 0, 0.70710678), (0, -0.70710678, 0, 0.70710678),
+                      (0.70710678, 0, 0, 0.70710678), (-0.70710678, 0, 0, 0.70710678)][int(rng.integers(0, 6))])
     cam = Camera(tuple(eye.astype(np.float32)), tuple(q.astype(np.float32)), float(rng.uniform(25, 100)), float(rng.uniform(0.2, 3.0)))
     W, H = int(rng.integers(9, 140)), int(rng.integers(9, 100))
+    if style == 6 and rng.random() < 0.5:
+        W, H = W | 1, H | 1          # odd extents: a pixel centre on the optical axis
     cam.setWidth(W); cam.setHeight(H); cam.calcRays()
     st = RenderSettings(bounceCount=int(rng.choice([0, 1, 2, 3, 4, 4, 5, 7])), sampleCount=int(rng.integers(1, 6)),
-                        antiAliasingEnabled=bool(rng.random() < 0.7), frameCount=int(rng.integers(0, 2 ** 31)),
+                        antiAliasingEnabled=bool(rng.random() < (0.3 if style == 6 else 0.7)), frameCount=int(rng.integers(0, 2 ** 31)),
                         maxDistance=float(rng.choice([100.0, 100.0, 30.0, 6.0, 1.5])), aoIntensity=float(rng.choice([0.01, 0.0, 0.3])))
     prev = None
     if rng.random() < 0.3:

@@ -142,7 +142,10 @@ def test_random_scene_soak(ctx):
     import soak_parity
     # ... and the seeds whose ray queries first showed hits lying before their object's box entry (rt_trace.h, trace_bvh)
     early = [1365, 1833, 1911, 1941, 2011, 3237, 3862, 3924, 4443, 4599, 4731, 5917]
-    bad = {seed: why for seed in list(range(48)) + early for why in [soak_parity.run_seed(ctx, seed, (0, 2, 1))] if why}
+    # ... the seeds whose collapsed objects (two axes scaled to zero: collinear triangles) showed hits no box can stand for
+    # (rt_commit.hip, thin_kernel), and a few of the later styles (axis-aligned grid scenes, collapsed axes)
+    thin = [106695, 108439, 108511] + list(range(100000, 100016))
+    bad = {seed: why for seed in list(range(48)) + early + thin for why in [soak_parity.run_seed(ctx, seed, (0, 2, 1))] if why}
     assert not bad, bad
 
 
