@@ -33,10 +33,20 @@ def _quat(rng, mostly_axis=False):
 def draw(seed):
     """(scene, camera, settings, rect, prev) of a seed."""
     rng = np.random.default_rng(1000 + seed)
-    style = seed % 6 if seed < 100000 else seed % 8   # (seeds below 100 000 keep the six styles they were first run with)
+    style = seed % 6 if seed < 100000 else (seed % 8 if seed < 200000 else seed % 10)   # (earlier seeds keep the styles they were first run with)
                               # 0 ordinary, 1 decades of scale, 2 touching grid, 3 duplicates, 4 flat + tiny, 5 dense pile,
-                              # 6 everything axis-aligned on a half-unit grid with an axis-aligned camera, 7 ordinary with a collapsed axis
+                              # 6 everything axis-aligned on a half-unit grid with an axis-aligned camera, 7 ordinary with a collapsed axis,
+                              # 8 the reference's own meshes (sword, bin: slivers and triangles of no area) in random poses, 9 far from the origin
     n_obj = int(rng.integers(1, 40 if style != 5 else 90))
+    if style == 8:
+        n_obj = int(rng.integers(1, 5))
+    real = None
+    if style == 8 and scenes.reference_assets() is not None:
+        bins, slots, _ = scenes.trashcan_meshes()
+        real = [[(scenes.sword_mesh(), 0)], [(m, 0) for m in bins]]
+    shift = np.zeros(3)
+    if style == 9:      # the whole scene, camera included, far out: every coordinate loses low bits
+        shift = rng.choice([-1.0, 1.0], 3) * float(rng.choice([300.0, 5000.0, 40000.0]))
     tex = int(rng.choice([32, 33, 64]))
     mats = []
     for k in range(int(rng.integers(1, 6))):
@@ -81,8 +91,13 @@ def draw(seed):
             pos, q = tuple(rng.uniform(-extent, extent, 3) * (1, 0.5, 1)), _quat(rng, mostly_axis=True)
         if style == 7 and rng.random() < 0.15:     # one axis collapsed: a singular model matrix, a non-finite inverse
             scl = tuple(0.0 if k == int(rng.integers(0, 3)) else v for k, v in enumerate(scl))
+        pos = tuple(np.asarray(pos, np.float64) + shift)
         placed.append((pos, q, scl))
         kind = int(rng.integers(0, 6)) if style != 2 else 1
+        if real is not None:
+            o = MeshObject(real[int(rng.integers(0, 2))], [mat], pos, _quat(rng, mostly_axis=True), tuple(rng.uniform(0.3, 1.5, 3)))
+            sc.addToScene(f"o{i}", o)
+            continue
         if kind == 0:
             o = Sphere(pos, q, scl); o.setMaterial(mat)
         elif kind == 1:
@@ -97,7 +112,7 @@ def draw(seed):
             o = MeshObject([(quad, 0), (box, 0)] if rng.random() < 0.5 else [(quad, 0)], [mat], pos, q, scl)
         sc.addToScene(f"o{i}", o)
     if rng.random() < 0.5:   # a floor everything stands in
-        fl = MeshObject([(scenes.merge_meshes([scenes.box_mesh((-30, -1.0, -30), (30, -0.7, 30))]), 0)], [mats[0]])
+        fl = MeshObject([(scenes.merge_meshes([scenes.box_mesh((-30, -1.0, -30), (30, -0.7, 30))]), 0)], [mats[0]], tuple(shift))
         sc.addToScene("floor", fl)
     # camera: somewhere around, looking at a point near the middle
     eye = rng.uniform(-1, 1, 3); eye = eye / np.linalg.norm(eye) * extent * rng.uniform(0.2, 3.0)
@@ -116,6 +131,7 @@ def draw(seed):
         eye[int(rng.integers(0, 3))] = float(rng.choice([-8.0, 8.0, 6.5]))
         q = np.array([(0, 0, 0, 1), (0, 1, 0, 0), (0, 0.70710678, 0, 0.70710678), (0, -0.70710678, 0, 0.70710678),
                       (0.70710678, 0, 0, 0.70710678), (-0.70710678, 0, 0, 0.70710678)][int(rng.integers(0, 6))])
+    eye = eye + shift
     cam = Camera(tuple(eye.astype(np.float32)), tuple(q.astype(np.float32)), float(rng.uniform(25, 100)), float(rng.uniform(0.2, 3.0)))
     W, H = int(rng.integers(9, 140)), int(rng.integers(9, 100))
     if style == 6 and rng.random() < 0.5:
@@ -194,8 +210,9 @@ def run_seed(ctx, seed, modes=(0, 2)):
     verts = np.concatenate(verts)
     a, b = verts[vr.integers(0, len(verts), n)], verts[vr.integers(0, len(verts), n)]
     tgt = np.where(vr.random((n, 1)) < 0.5, a, (0.5 * (a + b)).astype(np.float32))
-    tgt[: n // 3] = vr.uniform(-4, 4, (n // 3, 3))
-    org = vr.uniform(-9, 9, (n, 3)).astype(np.float32)
+    centre = np.median(verts, axis=0).astype(np.float64) if seed >= 200000 else np.zeros(3)   # (the far-out scenes of style 9)
+    tgt[: n // 3] = (centre + vr.uniform(-4, 4, (n // 3, 3))).astype(np.float32)
+    org = (centre + vr.uniform(-9, 9, (n, 3))).astype(np.float32)
     axis = vr.random(n) < 0.25
     k = vr.integers(0, 3, n)
     org[axis] = tgt[axis]
