@@ -191,7 +191,13 @@ int rt_render_noalloc(rt_ctx* ctx, const rt_camera_params* camera, const rt_rend
 
 /* closest-hit queries for caller-supplied rays (GPURaytracer.cu:247-265 semantics).
  * rays: 8 floats each (origin xyz, maxDistance, direction xyz, pad); out: 4 uint32 each
- * (object, mesh, triangle, float bits of t; all 0xFFFFFFFF on miss).  Host pointers. */
+ * (object, mesh, triangle, float bits of t; all 0xFFFFFFFF on miss).  Host pointers.
+ * Exact in every traversal mode, including the reference's order-dependent cases: ties between objects, hits that lie
+ * before their object's bounding-box entry, and the noise hits its triangle test reports on triangles of no area
+ * (collinear vertices), which no bounding box can stand for.  rt_render gives the same pixels as
+ * the reference in all of these but the last, where the hot kernels rely on a camera or bounce ray not passing within
+ * ~1e-7 of such a triangle's line (measured: never in 2e8 rays on the reference's sword); RT_OPT_TRAVERSAL = 1 removes
+ * that reliance at brute-force cost. */
 int rt_trace_rays(rt_ctx* ctx, const float* rays, int32_t nRays, uint32_t* out);
 
 /* HIP-event timing on the context stream: record into slot 0..13, elapsed between two slots
