@@ -94,8 +94,10 @@ enum rt_option {
                              2 = BVH, single persistent kernel.  All three give the same pixels. */
     RT_OPT_COUNTERS = 2,  /* reserved */
     RT_OPT_ACCUMULATE_STATS = 3, /* 1 = rt_render no longer zeroes the counters; setting it zeroes them once */
-    RT_OPT_WF_CHUNK = 4,  /* samples in flight per chunk of the wavefront pipeline (0 = default, 64 Mi); the
-                             workspace holds ~185 bytes per sample and lane (64 Mi samples x 3 lanes = 36 GB) */
+    RT_OPT_WF_CHUNK = 4,  /* samples in flight per chunk of the wavefront pipeline (0 = default, 192 Mi; halved down to
+                             64 Mi when the device cannot hold the workspace); the workspace holds ~185 bytes per sample
+                             and lane and is sized by the frame: 6 GB for 1080p x 16 spp, 98 GB (three chunks in flight)
+                             for 4K x 64 spp */
     RT_OPT_WF_LANES = 5,  /* chunks in flight at once, each on its own HIP stream (0 = default: one per chunk of the
                              frame, at most 3; 1..4) */
     RT_OPT_BUILDER = 6    /* acceleration structure built by rt_scene_commit: 0 = PLOC (default: slower commit, faster

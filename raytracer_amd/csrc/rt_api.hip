@@ -16,7 +16,8 @@
 namespace {
 
 constexpr size_t kWorkBytes = sizeof(uint32_t) * 512;
-constexpr size_t kWfChunkDefault = 64u << 20;
+constexpr size_t kWfChunkDefault = 192u << 20;   // samples; C3 (531 M): 8 chunks of 64 Mi 66.7 ms, 4 of 128 Mi 64.1, 3 of 177 M 62.2
+constexpr size_t kWfChunkFloor = 64u << 20;      // what the default falls back to, by halves, when the workspace does not fit the device
 constexpr int kWfLanesDefault = 3;        // most chunks in flight: the process has 4 hardware queues and one carries the copies, a 4th lane shares a queue and serialises
 constexpr size_t kCntBytes = sizeof(unsigned long long) * rt::kCounterSlots * rt::kCounterStride;
 
@@ -938,14 +939,25 @@ static int render_impl(rt_ctx* c, const rt_camera_params* cam, const rt_renderer
             // rays fixed the trace launches have no long tails left to hide); a frame of several chunks runs up
             // to three at a time, each one's tail under the others' bulk (C3, 8 chunks: 10.8 / 11.3 / 11.5 Grays/s
             // with 1 / 2 / 3 lanes).  An explicit RT_OPT_WF_LANES is taken as given, up to one lane per tile.
-            const size_t wantChunks = (tiles * perTile + c->optWfChunk - 1) / c->optWfChunk;
-            int lanes = c->optWfLanes ? (int)(tiles < (size_t)c->optWfLanes ? tiles : (size_t)c->optWfLanes)
+            size_t chunk = c->optWfChunk;
+            int lanes = 1;
+            size_t chunkTiles = 1;
+            hipError_t e = hipSuccess;
+            for (;;) {
+                const size_t wantChunks = (tiles * perTile + chunk - 1) / chunk;
+                lanes = c->optWfLanes ? (int)(tiles < (size_t)c->optWfLanes ? tiles : (size_t)c->optWfLanes)
                                       : (int)(wantChunks < (size_t)kWfLanesDefault ? wantChunks : (size_t)kWfLanesDefault);
-            lanes = lanes < 1 ? 1 : lanes;
-            size_t chunkTiles = (tiles + (size_t)lanes - 1) / (size_t)lanes;
-            const size_t capTiles = c->optWfChunk / perTile ? c->optWfChunk / perTile : 1;
-            if (chunkTiles > capTiles) chunkTiles = capTiles;
-            hipError_t e = ensure_wf(c, chunkTiles * perTile, rnd->bounceCount > 0 ? rnd->bounceCount : 0, lanes);
+                lanes = lanes < 1 ? 1 : lanes;
+                chunkTiles = (tiles + (size_t)lanes - 1) / (size_t)lanes;
+                const size_t capTiles = chunk / perTile ? chunk / perTile : 1;
+                if (chunkTiles > capTiles) chunkTiles = capTiles;
+                e = ensure_wf(c, chunkTiles * perTile, rnd->bounceCount > 0 ? rnd->bounceCount : 0, lanes);
+                // the default chunk is sized for a 288 GB device (up to 107 GB of workspace for a frame of three chunks); where
+                // that does not fit, smaller chunks do the same work a few percent slower.  An explicit RT_OPT_WF_CHUNK is taken as given.
+                if (e != hipErrorOutOfMemory || c->optWfChunk != kWfChunkDefault || chunk / 2 < kWfChunkFloor) break;
+                (void)hipGetLastError();
+                chunk /= 2;
+            }
             if (e != hipSuccess) return fail(c, RT_ERR_HIP, std::string("wavefront workspace: ") + hipGetErrorString(e));
             c->wf.n = lanes; c->wf.tilesPerChunk = (uint32_t)chunkTiles;
             RT_CHECK(c, hipEventRecord(c->evBegin, c->stream));
