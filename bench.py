@@ -14,7 +14,7 @@ One "step" = one frame (one pass of the hot path over W*H*spp samples).
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and `cpu_baseline`
 objects, and under "also" the same measurement of C4 (1 M triangles, 4K: the north-star target config) --
 at N = 1 as a whole frame, at N > 1 through the tile split.  The CPU baseline is the oracle (reference kernel
-logic, brute force) on a bounded centred crop of the same workload; it is a reported baseline, not the target.
+logic, brute force) on a bounded crop of the same workload, centred on the geometry; it is a reported baseline, not the target.
 
 roofline follows SURVEY.md 8(d): algorithmic bytes per ray = node fetches x 64 B + triangle tests x 48 B +
 hits x (12 + 96 + 16 per bound map) B + 16 B per pixel of output (+ 16 read when progressive); flops per ray =
@@ -273,7 +273,16 @@ def measure(job, workload, mode, steps, warmup, cpu_baseline):
             # not cull), so the crop shrinks with the scene to keep the CPU leg around 10-30 s
             budget = 2.2e10
             c = int(min(args.cpu_crop, W, H, max(8.0, (budget / (st.sampleCount * 1.8 * max(1, int(s.triangles)))) ** 0.5)))
-            x0, y0 = (W - c) // 2, (H - c) // 2
+            # centred on the geometry (the centroid of the pixels that differ from the frame's corner, i.e. from the sky), so
+            # that the CPU leg and the live parity figure are about hits, not about a patch of sky
+            fr = frame_t[..., :3]
+            mask = ((fr - fr[0, 0]).abs().amax(-1) > 1e-3)
+            if bool(mask.any()):
+                ys, xs = torch.nonzero(mask, as_tuple=True)
+                cx, cy = int(xs.float().mean().item()), int(ys.float().mean().item())
+            else:
+                cx, cy = W // 2, H // 2
+            x0, y0 = min(max(cx - c // 2, 0), W - c), min(max(cy - c // 2, 0), H - c)
             st.frameCount = warmup
             st.progressiveFrameCount = 0
             threads = orc.lib().or_num_threads()
@@ -286,7 +295,7 @@ def measure(job, workload, mode, steps, warmup, cpu_baseline):
             g = frame_t[y0:y0 + c, x0:x0 + c, :3].cpu().numpy()
             err = float(np.abs(g - ref[y0:y0 + c, x0:x0 + c, :3]).max())
             out["cpu_baseline"] = {"value": nq / cpu_s / 1e6, "unit": "Mrays/s", "cores": int(threads), "kind": "port",
-                                   "sample": f"centred {c}x{c} crop of frame {st.frameCount}, {st.sampleCount} spp, "
+                                   "sample": f"{c}x{c} crop at ({x0}, {y0}), centred on the geometry, of frame {st.frameCount}, {st.sampleCount} spp, "
                                              f"depth {st.bounceCount}: {nq} rays in {cpu_s:.1f} s",
                                    "gpu_vs_oracle_max_abs_on_crop": err}
     for fb in fbs:
