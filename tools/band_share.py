@@ -9,6 +9,7 @@ ctx = capi.Context(0)
 ctx.upload_scene(sc.flatten())
 ctx.set_camera_rays(cam.preTransformRays)
 fb = ctx.framebuffer(cam.width, cam.height)
+if os.environ.get('WF_CHUNK'): ctx.set_option(capi.OPT_WF_CHUNK, int(os.environ['WF_CHUNK'])); ctx.set_option(capi.OPT_WF_LANES, int(os.environ.get('WF_LANES', '0')))
 base = None
 for n in ([int(sys.argv[1])] if len(sys.argv) > 1 else (1, 2, 4, 8)):
     for r in sorted({0, n - 1}):
