@@ -1489,7 +1489,15 @@ __global__ __launch_bounds__(256) void wf_redo_kernel(const RenderArgs a, const 
     LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
     const uint32_t spp = a.sampleCount;
     const unsigned long long n = (unsigned long long)(*a.redoCount) * spp;
-    for (unsigned long long item = blockIdx.x * 256u + threadIdx.x; item < n; item += (unsigned long long)gridDim.x * 256u) {
+    // A whole path per lane, every lane on a walk of its own: as in wf_exact the items are spread over all the waves of
+    // the launch, `per` lanes of each, so that a short list costs one path's latency and not 64 of them in turn.
+    const unsigned long long waves = (unsigned long long)gridDim.x * 4u, wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long per = (n + waves - 1u) / waves;
+    per = per < 1u ? 1u : (per > 64u ? 64u : per);
+    for (unsigned long long base = wave * per; base < n; base += waves * per) {
+        const unsigned long long item = base + lane;
+        if (lane >= per || item >= n) continue;
         const uint32_t pix = a.redoList[item / spp], sidx = (uint32_t)(item % spp);
         int x, y;
         wf_pixel(a, w, pix, x, y);
