@@ -30,6 +30,9 @@ def _quat(rng, mostly_axis=False):
     return tuple(q / np.linalg.norm(q))
 
 
+SCALE = 1   # --scale: frame extents multiplied (same scenes, frames of several hundred pixels: many pieces per stripe, full batches)
+
+
 def draw(seed):
     """(scene, camera, settings, rect, prev) of a seed."""
     rng = np.random.default_rng(1000 + seed)
@@ -136,6 +139,7 @@ def draw(seed):
     W, H = int(rng.integers(9, 140)), int(rng.integers(9, 100))
     if style == 6 and rng.random() < 0.5:
         W, H = W | 1, H | 1          # odd extents: a pixel centre on the optical axis
+    W, H = W * SCALE, H * SCALE
     cam.setWidth(W); cam.setHeight(H); cam.calcRays()
     st = RenderSettings(bounceCount=int(rng.choice([0, 1, 2, 3, 4, 4, 5, 7])), sampleCount=int(rng.integers(1, 6)),
                         antiAliasingEnabled=bool(rng.random() < (0.3 if style == 6 else 0.7)), frameCount=int(rng.integers(0, 2 ** 31)),
@@ -307,7 +311,10 @@ def main():
     ap.add_argument("--count", type=int, default=100)
     ap.add_argument("--brute", action="store_true", help="also the reference-order brute-force mode")
     ap.add_argument("--sequence", action="store_true", help="edited live scenes through the GPURaytracer mirror instead of single frames")
+    ap.add_argument("--scale", type=int, default=1, help="multiply the frame extents (the oracle then needs seconds per seed)")
     a = ap.parse_args()
+    global SCALE
+    SCALE = max(1, a.scale)
     import torch
     torch.cuda.is_available()      # torch's HIP runtime first (tests/conftest.py)
     ctx = capi.Context(0)

@@ -149,6 +149,19 @@ def test_random_scene_soak(ctx):
     assert not bad, bad
 
 
+def test_random_scene_soak_large_frames(ctx):
+    """24 seeds of the same tool with the frame extents multiplied by six (frames of several hundred pixels a side: many
+    pieces per stripe, full shade batches, the noalloc / bands / chunks variants at those sizes), BVH pipelines, bit for bit."""
+    import soak_parity
+    soak_parity.SCALE = 6
+    try:
+        bad = {seed: why for seed in list(range(16)) + [100000, 100006, 100007, 200000, 200008, 200009, 200018, 200019]
+               for why in [soak_parity.run_seed(ctx, seed, (0, 2))] if why}
+    finally:
+        soak_parity.SCALE = 1
+    assert not bad, bad
+
+
 def test_live_scene_sequence_soak(ctx):
     """16 seeds of the sequence form of tests/soak_parity.py: a live scene edited between frames (objects moved, removed,
     added, material constants and maps changed, camera moved, progressive rendering toggled) through the GPURaytracer
