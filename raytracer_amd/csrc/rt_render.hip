@@ -1605,7 +1605,7 @@ void launch_render_wf(const RenderArgs& a, const WfLanes& L, int numCUs, hipStre
         const uint32_t needT = (nPieces + 3u) / 4u; // never more waves than 64-entry grabs
         if (gridT > needT) gridT = needT;
 #ifndef RT_SHADE_GRID
-#define RT_SHADE_GRID 8u
+#define RT_SHADE_GRID 12u // shade workgroups per CU (grid-stride over pieces / batches): 6 / 8 / 12 / 16 / 24 / 32 measured; 12 is 0.6 % ahead of 8 on C2, 1.3 % on C3
 #endif
         uint32_t gridS = (uint32_t)numCUs * RT_SHADE_GRID;
         if (gridS > nPieces) gridS = nPieces;
