@@ -50,7 +50,7 @@ def build_workload(name, args):
         label = "C1 cube+sphere (364 tris)"
     elif name == "c2":
         scene, cam, st = scenes.config2(args.width or 1920, args.height or 1080, args.spp or 16, args.depth or 4)
-        label = "C2 synthetic low-poly aeroplane stand-in + 1024^2 albedo texture"
+        label = scenes.workload_label("c2")
     else:
         fn = getattr(scenes, "config" + name[1:], None)
         if fn is None:
@@ -100,6 +100,10 @@ class Job:
         self.stream = torch.cuda.Stream(device=self.dev)
         torch.cuda.set_stream(self.stream)
         self.ctx.set_stream(self.stream.cuda_stream)
+        # frames in flight: frame i is rendered on lane i % inflight -- a workspace lane of the library (RT_OPT_WF_LANE) and a
+        # stream of its own -- so that one frame's last rays finish under the next frame's bulk
+        self.inflight = max(1, min(2, args.inflight))
+        self.lanes = [torch.cuda.Stream(device=self.dev) for _ in range(self.inflight)] if self.inflight > 1 else []
         self.ctx.set_option(capi.OPT_TRAVERSAL, 1 if args.brute else (0 if args.pipeline == "wavefront" else 2))
         if args.wf_lanes:
             self.ctx.set_option(capi.OPT_WF_LANES, args.wf_lanes)
@@ -140,7 +144,7 @@ def measure(job, workload, mode, steps, warmup, cpu_baseline):
         bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device=dev) for _ in range(2)]
         acc_t = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
         fbs = [ctx.framebuffer_wrap(b.data_ptr(), W, H) for b in bufs]
-        fa = multigpu.FrameAccumulator(dist, world, rank, bufs, acc_t)
+        fa = multigpu.FrameAccumulator(dist, world, rank, bufs, acc_t, streams=job.lanes or None)
         frame_t = bufs[0]
     else:
         # two frames in flight: the all_gather of frame i runs on a side stream while frame i + 1 renders
@@ -148,7 +152,30 @@ def measure(job, workload, mode, steps, warmup, cpu_baseline):
         fbs = [ctx.framebuffer_wrap(f.data_ptr(), W, H) for f in tc.frames]
         frame_t = tc.frames[0]
 
+    def on_main():
+        if job.lanes:
+            ctx.set_option(capi.OPT_WF_LANE, 0)
+            ctx.set_stream(job.stream.cuda_stream)
+
     def step(frame_base):
+        if not job.lanes:
+            return render_step(frame_base)
+        lane = frame_base % len(job.lanes)
+        ctx.set_option(capi.OPT_WF_LANE, lane)
+        ctx.set_stream(job.lanes[lane].cuda_stream)
+        with torch.cuda.stream(job.lanes[lane]):
+            render_step(frame_base)
+
+    def fork():     # the lanes start behind what the main stream holds
+        for s in job.lanes:
+            s.wait_stream(job.stream)
+
+    def join():     # ... and the main stream goes on behind the lanes
+        for s in job.lanes:
+            job.stream.wait_stream(s)
+        on_main()
+
+    def render_step(frame_base):
         st.progressiveFrameCount = 0
         if mode == "frames":
             st.frameCount = frame_base * world + rank
@@ -171,20 +198,24 @@ def measure(job, workload, mode, steps, warmup, cpu_baseline):
             tc.drain()
         job.barrier()
 
+    fork()
     for i in range(warmup):
         step(i)
+    join()
     barrier()
     note(job, f"{workload}: warm-up done")
     ctx.set_option(capi.OPT_ACCUMULATE_STATS, 1)
     barrier()
     ctx.event_record(0)
     t0 = time.perf_counter()
+    fork()
     for i in range(steps):
         step(warmup + i)
     if fa is not None:
         fa.drain()
     if tc is not None:
         tc.drain()
+    join()
     ctx.event_record(1)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -236,6 +267,7 @@ def measure(job, workload, mode, steps, warmup, cpu_baseline):
             "config": {"workload": label, "width": W, "height": H, "spp": int(st.sampleCount),
                        "depth": int(st.bounceCount), "triangles": int(s.triangles), "objects": len(flat.objects),
                        "mode": mode, "traversal": "brute" if args.brute else "bvh", "pipeline": args.pipeline,
+                       "frames_in_flight": max(1, len(job.lanes)),
                        "rays_per_frame": rays_total / steps / (world if mode == "frames" else 1), "scene_upload_s": upload_s,
                        "bvh_build_ms": float(s.commit_ms), "lib": ctx.L.rt_version().decode()},
             "roofline": {
@@ -324,6 +356,7 @@ def main():
     ap.add_argument("--wf-lanes", type=int, default=0, help="chunks in flight (HIP streams) of the wavefront pipeline (0 = library default)")
     ap.add_argument("--builder", type=int, default=0, help="acceleration structure builder: 0 = PLOC (library default), 1 = radix tree")
     ap.add_argument("--wf-chunk", type=int, default=0, help="samples in flight per chunk of the wavefront pipeline (0 = library default)")
+    ap.add_argument("--inflight", type=int, default=2, help="frames in flight per GPU (1 or 2): frame i is rendered on workspace lane and stream i %% inflight (RT_OPT_WF_LANE)")
     args = ap.parse_args()
 
     job = Job(args)

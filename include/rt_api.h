@@ -100,8 +100,15 @@ enum rt_option {
                              for 4K x 64 spp */
     RT_OPT_WF_LANES = 5,  /* chunks in flight at once, each on its own HIP stream (0 = default: one per chunk of the
                              frame, at most 3; 1..4) */
-    RT_OPT_BUILDER = 6    /* acceleration structure built by rt_scene_commit: 0 = PLOC (default: slower commit, faster
+    RT_OPT_BUILDER = 6,   /* acceleration structure built by rt_scene_commit: 0 = PLOC (default: slower commit, faster
                              frames), 1 = Karras radix tree (scenes re-committed every frame).  Same pixels. */
+    RT_OPT_WF_LANE = 7    /* frames in flight: the workspace lane (0 .. 3, default 0) the following rt_render / rt_render_bands
+                             calls use first.  Two calls that use different lanes AND run on different streams (rt_set_stream)
+                             may overlap on the GPU -- frame i + 1 fills the machine while frame i's last rays finish, which is
+                             worth 5-10 % of throughput on short frames (one rank's share of a frame split over 8 GPUs);
+                             calls on one lane must stay in stream order.  Each lane holds its own workspace (RT_OPT_WF_CHUNK).
+                             While calls overlap, rt_stats is meaningful only with RT_OPT_ACCUMULATE_STATS (the counters
+                             are shared), and kernel_ms not at all.  No counterpart in the synchronous reference. */
 };
 
 /* ---- context ---- */

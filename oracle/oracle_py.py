@@ -132,9 +132,11 @@ class OracleScene:
                          len(flat.materials), C.addressof(mats), len(flat.objects), C.addressof(objs))
 
 
-def render(flat, camera, settings, rect=None, prev=None, threads=0, want_ids=True):
+def render(flat, camera, settings, rect=None, prev=None, threads=0, want_ids=True, out=None, ids_out=None):
     """Render with the oracle.  camera: raytracer_amd.scene.Camera (rays computed);
-    settings: RenderSettings.  Returns (fb[H,W,4] float32, ids[H,W,4] uint32 or None, nQueries)."""
+    settings: RenderSettings.  Returns (fb[H,W,4] float32, ids[H,W,4] uint32 or None, nQueries).
+    out / ids_out: contiguous arrays to render into in place (out also holds the previous frame of a progressive
+    sequence): long sequences at large frame sizes then allocate and copy nothing per frame."""
     L = lib()
     sc = flat if isinstance(flat, OracleScene) else OracleScene(flat)
     W, H = camera.width, camera.height
@@ -146,8 +148,16 @@ def render(flat, camera, settings, rect=None, prev=None, threads=0, want_ids=Tru
                      int(bool(settings.antiAliasingEnabled)), int(settings.sampleCount))
     sky = OrSky((C.c_float * 4)(*settings.lightDirection), (C.c_float * 4)(*settings.lightColor),
                 (C.c_float * 4)(*settings.skyColor))
-    fb = np.zeros((H, W, 4), np.float32) if prev is None else np.ascontiguousarray(prev, np.float32).copy()
-    ids = np.full((H, W, 4), 0xFFFFFFFF, np.uint32) if want_ids else None
+    if out is not None:
+        assert out.dtype == np.float32 and out.shape == (H, W, 4) and out.flags.c_contiguous
+        fb = out
+    else:
+        fb = np.zeros((H, W, 4), np.float32) if prev is None else np.ascontiguousarray(prev, np.float32).copy()
+    if ids_out is not None:
+        assert ids_out.dtype == np.uint32 and ids_out.shape == (H, W, 4) and ids_out.flags.c_contiguous
+        ids = ids_out
+    else:
+        ids = np.full((H, W, 4), 0xFFFFFFFF, np.uint32) if want_ids else None
     x0, y0, x1, y1 = rect if rect is not None else (0, 0, W, H)
     n = L.or_render(C.addressof(sc.c), C.addressof(cam), C.addressof(rnd), C.addressof(sky),
                     x0, y0, x1, y1, fb.ctypes.data, _ptr(ids), threads)

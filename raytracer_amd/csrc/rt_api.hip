@@ -79,9 +79,10 @@ struct rt_ctx {
     float commitMs = 0.0f;
     int optTraversal = 0;
     int optWfLanes = 0;                       // 0 = by the number of chunks
+    int optWfLane = 0;                        // first workspace lane of the next render calls (RT_OPT_WF_LANE)
     int optBuilder = 0;                       // 0 = PLOC, 1 = radix tree
     size_t optWfChunk = kWfChunkDefault;     // samples in flight per chunk of the wavefront pipeline
-    void* wfArena = nullptr;                  // one allocation, carved per lane by wf_carve
+    void* wfArena = nullptr; size_t wfArenaBytes = 0;   // one allocation, carved per lane by wf_carve
     rt::WfLanes wf; size_t wfCapSlots = 0; int wfLevels = 0; int wfLanes = 0; // its lanes and their workspace
     int optCounters = 0;
     int optAccumulate = 0;
@@ -156,7 +157,8 @@ int check_material_desc(rt_ctx* c, const rt_material_desc* d)
 // cond(model) * 2^-23 * (extent + |translation|), and 1 / cos(incidence) times that for a grazing ray.  The band is
 // rel * (t + max |coordinate|); rel = 2e-4 covers cond * 1 / cos up to ~1700 (cond = 1 for any rigid or uniformly
 // scaled instance); beyond that it grows with the worst instance: 64 * cond * 2^-23.  A singular or non-finite
-// matrix makes it infinite: every ray that hits two objects then takes the exact in-order emulation.
+// matrix makes it 1e30 (finite, so that rel * 0 stays 0): every ray that hits two objects then takes the exact
+// in-order emulation; a ray that hits one object only does not (trav_result: otherT stays FLT_MAX).
 float band_rel_of(const float* model16, const float* inv16, int n)
 {
     double worst = 1.0;
@@ -169,11 +171,11 @@ float band_rel_of(const float* model16, const float* inv16, int n)
             nv = std::max(nv, (double)std::fabs(v[r]) + std::fabs(v[4 + r]) + std::fabs(v[8 + r]));
         }
         const double cond = nm * nv;
-        if (!(cond < 1e30)) return INFINITY;   // also NaN
+        if (!(cond < 1e30)) return 1e30f;   // also NaN
         worst = std::max(worst, cond);
     }
     const double rel = 64.0 * worst * 1.1920929e-07;
-    return (float)std::max(2e-4, rel);
+    return (float)std::min(1e30, std::max(2e-4, rel));
 }
 
 // Lays one lane's wavefront workspace out in [base, base + return value): ~177 bytes per sample in flight
@@ -199,34 +201,41 @@ size_t wf_carve(uint8_t* base, size_t slots, int levels, rt::WfBufs& w)
     w.hitM = (uint2*)take(8 * (queueWords / 2));
     w.out = (float4*)take(16 * slots);
     w.outRays = (uint8_t*)take(slots);
-    w.pixFlag = (uint32_t*)take(4 * ((slots + 63) & ~(size_t)63));
-    w.redoList = (uint32_t*)take(4 * ((slots + 63) & ~(size_t)63));
-    w.exactList = (uint32_t*)take(4 * (queueWords / 2));
+    w.redoSlots = (uint32_t*)take(4 * (queueWords / 2));
+    w.exactList = (uint32_t*)take(RT_EXACT_PASS ? 4 * (queueWords / 2) : 0);
     w.ctrl = (uint32_t*)take(4 * rt::wf_ctrl_words(levels));
     return off;
 }
 
 void free_wf(rt_ctx* c)
 {
-    hipFree(c->wfArena); c->wfArena = nullptr;
+    hipFree(c->wfArena); c->wfArena = nullptr; c->wfArenaBytes = 0;
     for (int j = 0; j < rt::kWfMaxLanes; j++) c->wf.bufs[j] = rt::WfBufs{};
     c->wfCapSlots = 0; c->wfLevels = 0; c->wfLanes = 0;
 }
 
-// workspace of the wavefront pipeline: one arena, `lanes` lanes of `slots` samples each
-hipError_t ensure_wf(rt_ctx* c, size_t slots, int levels, int lanes)
+// workspace of the wavefront pipeline: one arena, `lanes` lanes of `slots` samples each.
+// polite: the caller can do with less (the default chunk size, which halves itself): the arena then takes at most three
+// quarters of what the device has free -- a second context, or torch's caching allocator beside this one, keeps room --
+// and the arena in use is only given up once the new size has passed that test.
+hipError_t ensure_wf(rt_ctx* c, size_t slots, int levels, int lanes, bool polite)
 {
     if (slots <= c->wfCapSlots && levels <= c->wfLevels && lanes <= c->wfLanes) return hipSuccess;
-    hipError_t e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) return e;
     if (slots < c->wfCapSlots) slots = c->wfCapSlots;
     if (levels < c->wfLevels) levels = c->wfLevels;
     if (lanes < c->wfLanes) lanes = c->wfLanes;
-    free_wf(c);
     rt::WfBufs w;
     const size_t perLane = wf_carve(nullptr, slots, levels, w);
+    if (polite) {
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && perLane * (size_t)lanes > (freeB + c->wfArenaBytes) / 4 * 3) return hipErrorOutOfMemory;
+    }
+    hipError_t e = hipDeviceSynchronize();   // every stream: calls on other lanes (RT_OPT_WF_LANE) may be in flight in the arena that is about to go
+    if (e != hipSuccess) return e;
+    free_wf(c);
     e = hipMalloc((void**)&c->wfArena, perLane * (size_t)lanes);
     if (e != hipSuccess) { c->wfArena = nullptr; return e; }
+    c->wfArenaBytes = perLane * (size_t)lanes;
     for (int j = 0; j < lanes; j++) wf_carve((uint8_t*)c->wfArena + perLane * (size_t)j, slots, levels, c->wf.bufs[j]);
     c->wfCapSlots = slots; c->wfLevels = levels; c->wfLanes = lanes;
     return hipSuccess;
@@ -343,7 +352,10 @@ uint8_t* rt_image_load(const char* path, int32_t* width, int32_t* height, int32_
 
 void rt_image_free(uint8_t* pixels) { free(pixels); }
 
-const char* rt_version(void) { return "raytracer_amd 0.2.0 (gfx950)"; }
+#ifndef RT_BUILD_ID
+#define RT_BUILD_ID "unknown"
+#endif
+const char* rt_version(void) { return "raytracer_amd 0.3.0 (gfx950) build " RT_BUILD_ID; }   // the id: csrc/Makefile
 
 const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_createError.c_str(); }
 
@@ -440,6 +452,9 @@ int rt_set_option(rt_ctx* c, int option, int value)
     case RT_OPT_WF_LANES:
         if (value < 0 || value > rt::kWfMaxLanes) return fail(c, RT_ERR_INVALID, "RT_OPT_WF_LANES takes 0 (default) .. 4");
         c->optWfLanes = value; return RT_OK;
+    case RT_OPT_WF_LANE:
+        if (value < 0 || value >= rt::kWfMaxLanes) return fail(c, RT_ERR_INVALID, "RT_OPT_WF_LANE takes 0 .. 3");
+        c->optWfLane = value; return RT_OK;
     case RT_OPT_BUILDER:
         if (value < 0 || value > 1) return fail(c, RT_ERR_INVALID, "RT_OPT_BUILDER takes 0 (PLOC, default) or 1 (radix tree, fast rebuilds)");
         c->optBuilder = value; return RT_OK;
@@ -948,18 +963,20 @@ static int render_impl(rt_ctx* c, const rt_camera_params* cam, const rt_renderer
                 lanes = c->optWfLanes ? (int)(tiles < (size_t)c->optWfLanes ? tiles : (size_t)c->optWfLanes)
                                       : (int)(wantChunks < (size_t)kWfLanesDefault ? wantChunks : (size_t)kWfLanesDefault);
                 lanes = lanes < 1 ? 1 : lanes;
+                if (lanes > rt::kWfMaxLanes - c->optWfLane) lanes = rt::kWfMaxLanes - c->optWfLane;   // RT_OPT_WF_LANE: the lanes past the call's first
                 chunkTiles = (tiles + (size_t)lanes - 1) / (size_t)lanes;
                 const size_t capTiles = chunk / perTile ? chunk / perTile : 1;
                 if (chunkTiles > capTiles) chunkTiles = capTiles;
-                e = ensure_wf(c, chunkTiles * perTile, rnd->bounceCount > 0 ? rnd->bounceCount : 0, lanes);
+                const bool canHalve = c->optWfChunk == kWfChunkDefault && chunk / 2 >= kWfChunkFloor;
+                e = ensure_wf(c, chunkTiles * perTile, rnd->bounceCount > 0 ? rnd->bounceCount : 0, c->optWfLane + lanes, canHalve);
                 // the default chunk is sized for a 288 GB device (up to 107 GB of workspace for a frame of three chunks); where
                 // that does not fit, smaller chunks do the same work a few percent slower.  An explicit RT_OPT_WF_CHUNK is taken as given.
-                if (e != hipErrorOutOfMemory || c->optWfChunk != kWfChunkDefault || chunk / 2 < kWfChunkFloor) break;
+                if (e != hipErrorOutOfMemory || !canHalve) break;
                 (void)hipGetLastError();
                 chunk /= 2;
             }
             if (e != hipSuccess) return fail(c, RT_ERR_HIP, std::string("wavefront workspace: ") + hipGetErrorString(e));
-            c->wf.n = lanes; c->wf.tilesPerChunk = (uint32_t)chunkTiles;
+            c->wf.n = lanes; c->wf.first = c->optWfLane; c->wf.tilesPerChunk = (uint32_t)chunkTiles;
             RT_CHECK(c, hipEventRecord(c->evBegin, c->stream));
             rt::launch_render_wf(a, c->wf, c->numCUs, c->stream);
         }
@@ -1031,7 +1048,7 @@ int rt_render_noalloc(rt_ctx* c, const rt_camera_params* cam, const rt_renderer_
         size_t chunkTiles = capSlots / perTile;
         if (chunkTiles > tiles) chunkTiles = tiles;
         rt::WfLanes L = c->wf;
-        L.n = 1; L.tilesPerChunk = (uint32_t)chunkTiles;
+        L.n = 1; L.first = 0; L.tilesPerChunk = (uint32_t)chunkTiles;
         wf_carve((uint8_t*)c->scratchPtr, chunkTiles * perTile, levels, L.bufs[0]);
         rt::launch_render_wf(a, L, c->numCUs, c->stream);
     }

@@ -49,6 +49,7 @@ void launch_render(const RenderArgs& a, int mode, int numCUs, hipStream_t stream
 constexpr int kWfMaxLanes = 4;
 struct WfLanes {
     int n = 0;
+    int first = 0;                    // the call's lanes are first .. first + n - 1 (RT_OPT_WF_LANE); lane `first` runs on the caller's stream
     uint32_t tilesPerChunk = 0;
     hipStream_t streams[kWfMaxLanes] = {};
     hipEvent_t fork = nullptr;

@@ -129,7 +129,7 @@ struct SceneView {
 // sub-queues with their own counts and cursors (a single hot counter saturates at ~88 atomics/us).
 #ifndef RT_EXACT_PASS
 #define RT_EXACT_PASS 1   // 1: the tie-band rays of a level are listed and traced again by wf_exact before the level is shaded;
-#endif                    // 0: they flag their pixel for the redo launch instead (four launches per frame fewer, every flagged pixel's samples redone)
+#endif                    // 0: every tie-band ray sends its sample to the redo launch instead (four launches per frame fewer, whole paths redone)
 #ifndef RT_EXACT_GRID
 #define RT_EXACT_GRID 256u
 #endif
@@ -137,7 +137,7 @@ constexpr int kWfStripes = 64;
 constexpr int kWfCtrlStride = 32;          // words between two counters (one 128-byte line each)
 constexpr uint32_t kWfHole = 0xFFFFFFFFu;  // queue entry without a path
 constexpr uint32_t kWfMiss = 0x0FFFFFFFu;  // hitG: no triangle
-constexpr uint32_t kWfDanger = 0x80000000u; // hitG flag: the pixel must be re-rendered by the exact kernel
+constexpr uint32_t kWfDanger = 0x80000000u; // hitG flag: the sample's path must be traced again by the redo launch
 
 struct WfBufs {
     // per level, indexed by queue position (stripe, offset), ping-pong over levels like the queue:
@@ -151,10 +151,10 @@ struct WfBufs {
                          // and the object-cull fetches of a hit at once instead of one after the other
     float4* out;         // [slot] finished sample: exposure-corrected rgb, checksum bits
     uint8_t* outRays;    // [slot] closest-hit queries of the finished sample
-    uint32_t* pixFlag;   // [pixelInChunk] != 0: flagged for the redo launch
-    uint32_t* redoList;  // [pixelInChunk] the chunk's flagged pixels (a lane's chunks run one after the other, so they share it)
+    uint32_t* redoSlots; // [kWfStripes][subCap] the samples (slots) whose path the redo launch traces again with the exact in-order
+                         // emulation inline, listed under the stripe they live in (a sample is listed at most once: its path ends there)
     uint32_t* exactList; // [kWfStripes][subCap] hit positions of the level's rays inside the tie band, listed per stripe (RT_EXACT_PASS)
-    uint32_t* ctrl;      // [level][2][kWfStripes][kWfCtrlStride]: counts, cursors; then the redo count; then per level one tie-band count per stripe
+    uint32_t* ctrl;      // [level][2][kWfStripes][kWfCtrlStride]: counts, cursors; then one redo count per stripe; then per level one tie-band count per stripe
     uint32_t subCap;
     uint32_t nSlots;
     uint32_t nPix;       // pixels of the chunk = tiles * 64 (edge tiles include pixels outside the rectangle)
@@ -165,13 +165,16 @@ struct WfBufs {
 // words of WfBufs::ctrl for `levels` bounce levels, and where the two kinds of single counters sit in it
 __host__ __device__ inline size_t wf_ctrl_words(int levels)
 {
-    return (size_t)(levels + 1) * 2 * kWfStripes * kWfCtrlStride + (size_t)(1 + levels * kWfStripes) * kWfCtrlStride;
+    return (size_t)(levels + 1) * 2 * kWfStripes * kWfCtrlStride + (size_t)((1 + levels) * kWfStripes) * kWfCtrlStride;
 }
 __host__ __device__ inline size_t wf_ctrl_exact(int levels, int level, int stripe)
 {
-    return (size_t)(levels + 1) * 2 * kWfStripes * kWfCtrlStride + (size_t)(1 + level * kWfStripes + stripe) * kWfCtrlStride;
+    return (size_t)(levels + 1) * 2 * kWfStripes * kWfCtrlStride + (size_t)((1 + level) * kWfStripes + stripe) * kWfCtrlStride;
 }
-__host__ __device__ inline size_t wf_ctrl_redo(int levels) { return (size_t)(levels + 1) * 2 * kWfStripes * kWfCtrlStride; }
+__host__ __device__ inline size_t wf_ctrl_redo(int levels, int stripe)
+{
+    return (size_t)(levels + 1) * 2 * kWfStripes * kWfCtrlStride + (size_t)stripe * kWfCtrlStride;
+}
 struct RenderArgs {
     SceneView scene;
     // CameraParams (GPURaytracer.hpp:60-69)

@@ -602,6 +602,11 @@ __global__ __launch_bounds__(256, 3) void path_kernel(const RenderArgs a)
             const uint32_t sidx = iter * 4u + z;
             seed = sample_seed(a, x, y, sidx);
             ray = setup_ray(a, x, y, seed);
+            // a camera ray next to a listed thin triangle's line (wf_gen says why): the pixel goes to the redo launch
+#ifndef RT_DIAG_NO_THIN_GEN
+            for (uint32_t k = 0; k < a.scene.nThin; k++)
+                if (thin_near(a.scene.thin[k], ray)) flagged = true;
+#endif
             acc.ox = acc.oy = acc.oz = 0.0f; acc.bx = acc.by = acc.bz = 1.0f;
             bounce = 0;
             hasPath = a.bounceCount > 0;
@@ -816,6 +821,15 @@ __device__ __forceinline__ bool wf_pixel(const RenderArgs& a, const WfBufs& w, u
 // travels in the spare word of the beta record
 __device__ __forceinline__ uint32_t wf_level0_slot(uint32_t stripe, uint32_t off) { return ((off >> 8) * kWfStripes + stripe) * 256u + (off & 255u); }
 __device__ __forceinline__ bool wf_is_hole(const float4& d) { return d.x == 0.0f && d.y == 0.0f && d.z == 0.0f; }
+__device__ __forceinline__ int wf_levels(const RenderArgs& a) { return a.bounceCount > 0 ? a.bounceCount : 0; }
+// The sample's path is traced again from the camera by the redo launch, with the exact in-order emulation inline
+// (tie bands between objects, culled winners, stack overflows, camera rays next to a listed thin triangle); its path in
+// the pipeline ends where this is called, so a sample is listed once, under the stripe it lives in (a list cannot overflow).
+__device__ __forceinline__ void wf_redo_sample(const RenderArgs& a, const WfBufs& w, uint32_t stripe, uint32_t slot)
+{
+    const uint32_t k = atomicAdd(w.ctrl + wf_ctrl_redo(wf_levels(a), (int)stripe), 1u);
+    w.redoSlots[(size_t)stripe * w.subCap + k] = slot;
+}
 
 // level 0: camera rays (:140-163) in slot order; holes for pixels outside the rectangle
 __global__ __launch_bounds__(256) void wf_gen_kernel(const RenderArgs a, const WfBufs w)
@@ -829,16 +843,17 @@ __global__ __launch_bounds__(256) void wf_gen_kernel(const RenderArgs a, const W
     }
     const uint32_t piece = blockIdx.x, stripe = piece % kWfStripes, off = (piece / kWfStripes) * 256u + threadIdx.x;
     float4 entry = make_float4(0.0f, 0.0f, 0.0f, 0.0f); // a hole (pixel outside the rectangle, or no bounce loop): the zero direction
+    bool traced = false;
     if (i < w.nSlots) {
         const uint32_t spp = a.sampleCount;
         const uint32_t pix = i / spp, sidx = i - pix * spp;
         int x, y;
         if (wf_pixel(a, w, pix, x, y)) {
-            if (sidx == 0) w.pixFlag[pix] = 0u;
             uint32_t seed = sample_seed(a, x, y, sidx);
             const Ray ray = setup_ray(a, x, y, seed);
             if (a.bounceCount > 0) { // outgoing light 0, beta 1, checksum 0 and the slot (wf_level0_slot): wf_shade(0) supplies them
                 entry = make_float4(ray.dx, ray.dy, ray.dz, __uint_as_float(seed));
+                traced = true;
             } else { // the bounce loop does not run: radiance 0 (:172)
                 if (sidx == 0 && a.ids) {
                     uint32_t* idp = reinterpret_cast<uint32_t*>(a.ids + ((size_t)y * (size_t)a.width + (size_t)x));
@@ -850,6 +865,41 @@ __global__ __launch_bounds__(256) void wf_gen_kernel(const RenderArgs a, const W
             }
         }
     }
+    // The triangles no box can stand for (rt_commit.hip, thin_kernel; rt_trace.h, thin_near): a ray that passes within rounding
+    // of the LINE such a triangle lies on can "hit" it wherever along that line it sits, so no walk of the tree finds it.  Camera
+    // rays are the rays that can be aimed at such a line by construction (an axis-aligned camera without anti-aliasing over
+    // gridded geometry puts pixel centres on vertices), so every camera ray is tested against every listed line here, and one
+    // that comes near goes to the redo launch, whose walks test the listed triangles (bvh_walk).  With the origin common to all
+    // camera rays the test of thin_near, |w . (d x u)| <= rad |d x u|, becomes |d . (u x w)| <= rad (as |d x u| <= 1: a superset,
+    // the plane through the camera and the line instead of the line; 1.25 covers the rounding of the other association), with
+    // u x w and rad worked out once per workgroup and line: seven operations per ray and line.
+#ifndef RT_DIAG_NO_THIN_GEN   // diagnostic build: shows that tests/thin_scene.py fails without this test
+    if (a.scene.nThin != 0u && a.bounceCount > 0) {
+        __shared__ float4 thinPlane[64];
+        bool near = false;
+        for (uint32_t base = 0; base < a.scene.nThin; base += 64u) {
+            __syncthreads();
+            if (threadIdx.x < 64u && base + threadIdx.x < a.scene.nThin) {
+                const ThinTri r = a.scene.thin[base + threadIdx.x];
+                const float wx = r.px - a.camOrigin[0], wy = r.py - a.camOrigin[1], wz = r.pz - a.camOrigin[2];
+                const float rad = 1.25f * (r.k * (wx * wx + wy * wy + wz * wz + r.len2) + 1e-30f);
+                thinPlane[threadIdx.x] = make_float4(r.uy * wz - r.uz * wy, r.uz * wx - r.ux * wz, r.ux * wy - r.uy * wx, rad);
+            }
+            __syncthreads();
+            const uint32_t cnt = a.scene.nThin - base < 64u ? a.scene.nThin - base : 64u;
+            if (traced)
+                for (uint32_t k = 0; k < cnt; k++) {
+                    const float4 pl = thinPlane[k];
+                    const float num = entry.x * pl.x + entry.y * pl.y + entry.z * pl.z;
+                    near = near || !(num * num > pl.w * pl.w);   // NaN stays in
+                }
+        }
+        if (near) {
+            wf_redo_sample(a, w, stripe, i);
+            entry = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // a hole for the pipeline
+        }
+    }
+#endif
     w.rayD[wf_pos(w, 0, stripe, off)] = entry;
 }
 
@@ -936,9 +986,10 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
 #endif
         // ---- results of the lanes that finished
         if (have && !trav_running(T)) {
-            // a hit of another object inside the tie band, or a dropped stack entry: the pixel is flagged for the redo
-            // launch, which traces it with the exact in-order emulation inline (6e-6 of the rays on C2 / C4, 4e-4 on C5;
-            // a pass per level over a list of such rays cost four near-empty launches per frame, 0.12 ms of C2's 6.8)
+            // a hit of another object inside the tie band, or a dropped stack entry: the hit record carries kWfDanger and
+            // wf_shade sends the SAMPLE to the redo launch, which traces its path again with the exact in-order emulation
+            // inline (1e-5 of the rays on C2, 2e-3 on C4, 7e-4 on C5).  RT_EXACT_PASS = 1 instead lists the tie-band rays and
+            // traces them again between the level's trace and shade launches (wf_exact: one more launch per level)
             bool band = false;
             const Hit h = trav_result(T, ray, band, a.scene.bandRel);
             const bool over = stack.dropped;
@@ -1289,6 +1340,13 @@ __device__ __forceinline__ void shade_entry(const RenderArgs& a, const WfBufs& w
     Hit h; h.t = 0.0f; h.b0 = h.b1 = h.b2 = 0.0f;
     h.gid = (hM.x & kWfMiss) == kWfMiss ? kNoHit : (hM.x & kWfMiss);
     bool danger = (hM.x & kWfDanger) != 0u;
+    if (danger) { // tie band / stack overflow: the redo launch traces the whole path again, nothing of this one is kept
+#ifdef RT_DEBUG_FLAGS
+        printf("redo: level %d slot %u (trace flag) gid %u\n", level, o.slot, hM.x & kWfMiss);
+#endif
+        wf_redo_sample(a, w, stripe, o.slot);
+        return;
+    }
     uint32_t cullObj = kNoHit;
     float m0 = 0.0f;
     if (h.gid != kNoHit) { // the ray's origin and the hit's distance / barycentrics matter to a hit only
@@ -1300,10 +1358,14 @@ __device__ __forceinline__ void shade_entry(const RenderArgs& a, const WfBufs& w
     }
     uint32_t primary[3] = { kNoHit, kNoHit, kNoHit };
     o.more = shade_segment(a, h, ray, seed, sidx, level, acc, st, checksum, primary, cullObj, m0, &danger);
+    if (danger) { // the winner's object fails its cull, or enters its box past the tie band (shade_segment)
 #ifdef RT_DEBUG_FLAGS
-    if (danger) printf("flag: level %d pix %u overflow %d gid %u\n", level, pix, (int)((hM.x & kWfDanger) != 0u), h.gid);
+        printf("redo: level %d slot %u (cull) gid %u\n", level, o.slot, h.gid);
 #endif
-    if (danger) w.pixFlag[pix] = 1u;
+        wf_redo_sample(a, w, stripe, o.slot);
+        o.more = false;
+        return;
+    }
     if (level == 0 && sidx == 0 && a.ids) {
         int x, y;
         wf_pixel(a, w, pix, x, y);
@@ -1432,9 +1494,8 @@ __global__ __launch_bounds__(256, DEAL ? RT_SHADE_OCC : RT_SHADE_OCC + 1) void w
     flush_stats(a, st, wgCnt);
 }
 
-// :88-137: per pixel, the sample results in the reference's summation order.
-// PASS 0: every pixel of the chunk; flagged ones are listed for wf_redo instead of written.
-// PASS 1: the listed pixels, after wf_redo has replaced their samples.
+// :88-137: per pixel, the sample results in the reference's summation order (after wf_redo has supplied the
+// samples that left the pipeline).
 __device__ __forceinline__ void wf_resolve_pixel(const RenderArgs& a, const WfBufs& w, uint32_t pix, int x, int y, LaneStats& st)
 {
     const uint32_t spp = a.sampleCount;
@@ -1455,50 +1516,57 @@ __device__ __forceinline__ void wf_resolve_pixel(const RenderArgs& a, const WfBu
     write_pixel(a, x, y, tr, tg, tb, nullptr, checksum);
 }
 
-template <int PASS>
 __global__ __launch_bounds__(256) void wf_resolve_kernel(const RenderArgs a, const WfBufs w)
 {
     __shared__ uint32_t wgCnt[8];
     LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
     int x, y;
-    if (PASS == 0) {
-        const uint32_t pix = blockIdx.x * 256u + threadIdx.x;
-        if (pix < w.nPix && wf_pixel(a, w, pix, x, y)) {
-            if (w.pixFlag[pix] != 0u) a.redoList[atomicAdd(a.redoCount, 1u)] = pix;
-            else wf_resolve_pixel(a, w, pix, x, y, st);
-        }
-    } else {
-        const uint32_t n = *a.redoCount;
-        for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) {
-            const uint32_t pix = a.redoList[k];
-            wf_pixel(a, w, pix, x, y);
-            wf_resolve_pixel(a, w, pix, x, y, st);
-        }
-    }
+    const uint32_t pix = blockIdx.x * 256u + threadIdx.x;
+    if (pix < w.nPix && wf_pixel(a, w, pix, x, y)) wf_resolve_pixel(a, w, pix, x, y, st);
     flush_stats(a, st, wgCnt);
 }
 
-// The flagged pixels again, one lane per sample, with the exact in-order emulation inline
-// (closest_hit<2>): tie bands between objects, culled winners, stack overflows.
+// The samples that left the pipeline (wf_redo_sample) again from the camera, one lane per path, with the exact
+// in-order emulation inline (closest_hit<2>): tie bands between objects, culled winners, stack overflows, camera
+// rays next to a listed thin triangle.  Exits at once when the lists are empty.
 __global__ __launch_bounds__(256) void wf_redo_kernel(const RenderArgs a, const WfBufs w)
 {
     __shared__ uint32_t ldsStack[kLdsStack * kBlock];
     __shared__ uint32_t wgCnt[8];
+    // the stripes' lists read as one: entry i belongs to the last stripe whose running total is <= i
+    __shared__ uint32_t listBase[kWfStripes + 1];
+    if (threadIdx.x < 64) {
+        const uint32_t cnt = w.ctrl[wf_ctrl_redo(wf_levels(a), (int)threadIdx.x)];
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+            if ((int)threadIdx.x >= d) incl += up;
+        }
+        listBase[threadIdx.x + 1] = incl;
+        if (threadIdx.x == 0) listBase[0] = 0u;
+    }
+    __syncthreads();
+    const uint32_t n = listBase[kWfStripes];
     uint32_t ovf[kStackDepth - kLdsStack];
     Stack stack; stack.lds = ldsStack + threadIdx.x; stack.ovf = ovf;
     LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
     const uint32_t spp = a.sampleCount;
-    const unsigned long long n = (unsigned long long)(*a.redoCount) * spp;
-    // A whole path per lane, every lane on a walk of its own: as in wf_exact the items are spread over all the waves of
-    // the launch, `per` lanes of each, so that a short list costs one path's latency and not 64 of them in turn.
-    const unsigned long long waves = (unsigned long long)gridDim.x * 4u, wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    // A whole path per lane, every lane on a walk of its own, one dependent fetch after the other: the items are spread over
+    // all the waves of the launch, `per` lanes of each, so that a short list costs one path's latency and not 64 of them in turn.
+    const uint32_t waves = gridDim.x * 4u, wave = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t lane = threadIdx.x & 63u;
-    unsigned long long per = (n + waves - 1u) / waves;
+    uint32_t per = (n + waves - 1u) / waves;
     per = per < 1u ? 1u : (per > 64u ? 64u : per);
-    for (unsigned long long base = wave * per; base < n; base += waves * per) {
-        const unsigned long long item = base + lane;
+    for (uint32_t base = wave * per; base < n; base += waves * per) {
+        const uint32_t item = base + lane;
         if (lane >= per || item >= n) continue;
-        const uint32_t pix = a.redoList[item / spp], sidx = (uint32_t)(item % spp);
+        uint32_t ls = 0;
+#pragma unroll
+        for (uint32_t step = kWfStripes / 2; step > 0; step >>= 1)
+            if (listBase[ls + step] <= item) ls += step;
+        const uint32_t slot = w.redoSlots[(size_t)ls * w.subCap + (item - listBase[ls])];
+        const uint32_t pix = slot / spp, sidx = slot - pix * spp;
         int x, y;
         wf_pixel(a, w, pix, x, y);
         uint32_t seed = sample_seed(a, x, y, sidx), checksum = 0;
@@ -1515,7 +1583,7 @@ __global__ __launch_bounds__(256) void wf_redo_kernel(const RenderArgs a, const 
             idp[0] = primary[0]; idp[1] = primary[1]; idp[2] = primary[2];
         }
     }
-    st.rays = 0; // counted by the second resolve pass from outRays
+    st.rays = 0; // counted by wf_resolve from outRays
     flush_stats(a, st, wgCnt);
 }
 
@@ -1587,18 +1655,16 @@ void launch_render_wf(const RenderArgs& a, const WfLanes& L, int numCUs, hipStre
     const int used = (int)(nChunks < (uint32_t)L.n ? nChunks : (uint32_t)L.n);
     if (used > 1) {
         hipEventRecord(L.fork, mainStream);
-        for (int j = 1; j < used; j++) hipStreamWaitEvent(L.streams[j], L.fork, 0);
+        for (int j = 1; j < used; j++) hipStreamWaitEvent(L.streams[L.first + j], L.fork, 0);
     }
     for (uint32_t k = 0; k < nChunks; k++) {
         const int j = (int)(k % (uint32_t)used);
-        hipStream_t stream = j == 0 ? mainStream : L.streams[j];
-        WfBufs w = L.bufs[j];
+        hipStream_t stream = j == 0 ? mainStream : L.streams[L.first + j];
+        WfBufs w = L.bufs[L.first + j];
         const uint32_t nt = (nTiles - k + nChunks - 1) / nChunks; // tiles k, k + nChunks, ...
         w.tileBegin = k; w.tileStride = nChunks; w.nPix = nt * 64u; w.nSlots = w.nPix * spp;
         const uint32_t nPieces = (w.nSlots + 255u) / 256u;
         RenderArgs c = b;
-        c.redoCount = w.ctrl + wf_ctrl_redo(levels);
-        c.redoList = w.redoList; // per lane: at most the chunk's own pixels are listed, and the lane's chunks run in stream order
         hipMemsetAsync(w.ctrl, 0, sizeof(uint32_t) * ctrlWords, stream);
         hipLaunchKernelGGL(wf_gen_kernel, dim3(nPieces), dim3(256), 0, stream, c, w);
         uint32_t gridT = (uint32_t)numCUs * RT_WF_OCC;
@@ -1622,16 +1688,15 @@ void launch_render_wf(const RenderArgs& a, const WfLanes& L, int numCUs, hipStre
             if (level == 0) hipLaunchKernelGGL((wf_shade_kernel<false>), dim3(gridS), dim3(256), 0, stream, c, w, level);
             else hipLaunchKernelGGL((wf_shade_kernel<true>), dim3(gridS), dim3(256), 0, stream, c, w, level);
         }
-        hipLaunchKernelGGL((wf_resolve_kernel<0>), dim3((w.nPix + 255u) / 256u), dim3(256), 0, stream, c, w);
-        // the pixels this chunk flagged, one lane per sample; both launches exit at once when there is none
+        // the samples that left the pipeline, one lane per path (exits at once when there is none); then every pixel's sum
         uint32_t gridR = (w.nSlots + 255u) / 256u;
         if (gridR > (uint32_t)numCUs * 2u) gridR = (uint32_t)numCUs * 2u; // 2 workgroups per CU is what its 222 VGPRs admit; the loop strides
         hipLaunchKernelGGL(wf_redo_kernel, dim3(gridR), dim3(256), 0, stream, c, w);
-        hipLaunchKernelGGL((wf_resolve_kernel<1>), dim3(gridR > 64u ? 64u : gridR), dim3(256), 0, stream, c, w);
+        hipLaunchKernelGGL(wf_resolve_kernel, dim3((w.nPix + 255u) / 256u), dim3(256), 0, stream, c, w);
     }
     for (int j = 1; j < used; j++) {
-        hipEventRecord(L.join[j], L.streams[j]);
-        hipStreamWaitEvent(mainStream, L.join[j], 0);
+        hipEventRecord(L.join[L.first + j], L.streams[L.first + j]);
+        hipStreamWaitEvent(mainStream, L.join[L.first + j], 0);
     }
 }
 

@@ -100,8 +100,9 @@ __device__ __forceinline__ bool tri_test_core(const TriRay& q, float maxDist, fl
 
     const float invDet = 1 / det;
     const float t = tScaled * invDet;
-    // (double)t < 0.001, t > maxDist, and the reference's '<' against FLT_MAX that a FLT_MAX / NaN distance never wins (:421)
-    if (((double)t < 0.001) | (t > maxDist) | !(t < FLT_MAX)) return false;
+    // t < 0.001 (the reference compares in binary64; 0.001f is the smallest binary32 >= 0.001, so t < 0.001f decides the same
+    // for every binary32 t), t > maxDist, and the reference's '<' against FLT_MAX that a FLT_MAX / NaN distance never wins (:421)
+    if ((t < 0.001f) | (t > maxDist) | !(t < FLT_MAX)) return false;
 
     tOut = t; b0Out = e0 * invDet; b1Out = e1 * invDet; b2Out = e2 * invDet;
     if (tsOut) *tsOut = tScaled;
@@ -693,7 +694,7 @@ __device__ __forceinline__ Hit trace_bvh(const SceneView& s, Ray& ray, Stack& st
     if (best.gid == kNoHit) return best;
     const float limit = best.t + band_of(best.t, rayScale, s.bandRel);
     if (bestTmin > limit) { slowPath++; return trace_bvh_exact(s, ray, q, br, m0, stack, cnt); }
-    if (otherT <= limit) { // first the one-walk replay on the object table, then the general emulation
+    if (otherT < FLT_MAX && otherT <= limit) { // first the one-walk replay on the object table, then the general emulation
         slowPath++;
         Hit out;
         bool needAll = false;
@@ -852,7 +853,7 @@ __device__ __forceinline__ Hit trav_result(const Trav& T, Ray& ray, bool& danger
 {
     if (T.best.gid != kNoHit) {
         const float limit = T.best.t + band_of(T.best.t, T.rayScale, bandRel);
-        if (T.otherT <= limit) danger = true;
+        if (T.otherT < FLT_MAX && T.otherT <= limit) danger = true;   // FLT_MAX = no other object hit (the limit may be infinite)
         ray.maxDist = T.best.t;
     }
     return T.best;

@@ -171,22 +171,40 @@ class FrameAccumulator:
         fa.drain()               # all reduces finished, acc complete on dst
     """
 
-    def __init__(self, dist, world, rank, buffers, acc, dst=0, exchange=None):
-        """exchange: launch the reduce even with one rank (default: only when world > 1); see TileCompositor."""
+    def __init__(self, dist, world, rank, buffers, acc, dst=0, exchange=None, streams=None):
+        """exchange: launch the reduce even with one rank (default: only when world > 1); see TileCompositor.
+        streams: two torch streams, one per buffer, when the two frames in flight are rendered on streams of their own
+        (rt_set_option RT_OPT_WF_LANE): buffer b's reduce and its addition then run on streams[b], into a partial sum per
+        buffer (two streams adding into one tensor would race), and drain() folds the partial sums into acc on the
+        caller's stream.  The caller renders frame i under torch.cuda.stream(streams[i & 1])."""
         assert len(buffers) == 2
         self.dist, self.world, self.rank, self.buffers, self.acc, self.dst = dist, world, rank, buffers, acc, dst
         self.exchange = world > 1 if exchange is None else bool(exchange)
         self.pending = [None, None]
         self.dirty = [False, False]
         self.host = None
+        self.streams = streams
+        self.partials = None
+        if streams is not None:
+            assert len(streams) == 2
+            import torch
+            self.torch = torch
+            self.partials = [torch.zeros_like(acc), torch.zeros_like(acc)] if rank == dst else None
 
     def _finish(self, b):
+        if self.streams is not None:
+            with self.torch.cuda.stream(self.streams[b]):
+                self._finish_on_current(b, self.partials[b] if self.partials is not None else None)
+        else:
+            self._finish_on_current(b, self.acc)
+
+    def _finish_on_current(self, b, into):
         if self.pending[b] is not None:
             self.pending[b].wait()
             self.pending[b] = None
         if self.dirty[b]:
             if self.rank == self.dst:
-                self.acc.add_(self.buffers[b])
+                into.add_(self.buffers[b])
             self.dirty[b] = False
 
     def acquire(self, i):
@@ -213,3 +231,13 @@ class FrameAccumulator:
     def drain(self):
         self._finish(0)
         self._finish(1)
+        if self.streams is not None:
+            cur = self.torch.cuda.current_stream()
+            for s in self.streams:
+                cur.wait_stream(s)
+            if self.partials is not None:
+                for p in self.partials:
+                    self.acc.add_(p)
+                    p.zero_()
+                for s in self.streams:   # the partial sums are not touched again before this
+                    s.wait_stream(cur)

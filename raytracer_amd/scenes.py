@@ -130,13 +130,19 @@ def lowpoly_plane_mesh():
 
 def config2(width=1920, height=1080, spp=16, depth=4, tex_size=1024):
     """C2 (BASELINE.json configs[1]): low-poly model + 1024^2 albedo texture, 1080p, 16 spp,
-    depth 4.  The aeroplane OBJ is not in the reference checkout, so the mesh is the synthetic
-    stand-in above and the texture is procedural (same size/format as `Airplane Texture.png`).
-    A thin ground slab (a zero-thickness quad is invisible in the reference) and
+    depth 4.  The aeroplane OBJ is not in the reference checkout (*.obj is git-ignored there), so the
+    mesh is the synthetic stand-in above; the albedo map is the reference's own
+    res/basiclowpoly/Airplane Texture.png (the bytes its stbi_load returns, tests/golden/ref_assets.npz;
+    Texture upload: Material.cu:179-205) at the default size, a procedural map at any other size or
+    without the fixture.  A thin ground slab (a zero-thickness quad is invisible in the reference) and
     two props give the bounce rays something to hit."""
     scene = Scene()
     paint = Material("PlanePaint", (0.8, 0.8, 0.8, 1.0), 0.45, 0.1)
-    paint.setAlbedoTexture(Texture(procedural_texture(tex_size, 7, "albedo")))
+    ra = reference_assets()
+    if ra is not None and tex_size == 1024 and "airplane_albedo" in ra:
+        paint.setAlbedoTexture(Texture(ra["airplane_albedo"]))
+    else:
+        paint.setAlbedoTexture(Texture(procedural_texture(tex_size, 7, "albedo")))
     ground = Material("Ground", (0.45, 0.5, 0.4, 1.0), 0.9, 0.0)
     lamp = Material("Lamp", (1.0, 0.9, 0.7, 1.0), 0.5, 0.0, (1.0, 0.85, 0.6), 4.0)
     chrome = Material("Chrome", (0.9, 0.9, 0.95, 1.0), 0.15, 1.0)
@@ -192,7 +198,9 @@ def workload_label(name):
     """bench.py's config.workload string: says whether the reference's geometry or a stand-in is rendered."""
     real = reference_assets() is not None
     return {
-        "c3": "C3 pbrsword: " + ("reference geometry (murasama.fbx flattened, 8 972 tris) + its roughness / metallic maps, procedural albedo + normal"
+        "c2": "C2 low-poly aeroplane (synthetic stand-in mesh: the OBJ is absent from the reference checkout) + "
+              + ("the reference's 1024^2 Airplane Texture.png as albedo" if real else "a procedural 1024^2 albedo map"),
+        "c3": "C3 pbrsword: " + ("reference geometry (murasama.fbx flattened, 8 972 tris) + its Base_Color / Roughness / Metallic maps, procedural normal map (the reference's is a missing blob)"
                                  if real else "synthetic stand-in mesh and maps") + ", 2048^2 x 4 maps",
         "c4": "C4 331 x lowpolypbrtrash: " + ("reference geometry (model.dae flattened, 6 meshes, 3 024 tris) x 331 = 1 000 944 tris, metalmaterial roughness / metalness maps"
                                                 if real else "synthetic stand-in meshes") + ", 2 PBR material sets x 4 maps",
@@ -221,14 +229,17 @@ def sword_mesh():
 def config3(width=3840, height=2160, spp=64, depth=4, tex_size=2048):
     """C3 (BASELINE.json configs[2]): the PBR sword with albedo / normal / roughness / metal 2048^2 textures,
     3840x2160, 64 spp.  With tests/golden/ref_assets.npz the geometry is the reference's murasama.fbx and the
-    roughness / metallic maps are its own; albedo (16-bit, 3.4 MB: not in the fixture) and the normal map
-    (missing from the reference checkout) are procedural.  Without the fixture everything is a stand-in."""
+    base colour / roughness / metallic maps are its own (the 16-bit base colour as stb_image reduces it, >> 8);
+    the normal map (missing from the reference checkout) is procedural.  Without the fixture everything is a stand-in."""
     width, height, spp, depth = width or 3840, height or 2160, spp or 64, depth or 4
     scene = Scene()
     steel = Material("Steel", (0.8, 0.8, 0.85, 1.0), 0.3, 1.0)
-    steel.setAlbedoTexture(Texture(procedural_texture(tex_size, 11, "albedo")))
-    steel.setNormalTexture(Texture(procedural_texture(tex_size, 12, "normal")))
     ra = reference_assets()
+    if ra is not None and tex_size == 2048 and "sword_base_color" in ra:
+        steel.setAlbedoTexture(Texture(ra["sword_base_color"]))
+    else:
+        steel.setAlbedoTexture(Texture(procedural_texture(tex_size, 11, "albedo")))
+    steel.setNormalTexture(Texture(procedural_texture(tex_size, 12, "normal")))
     if ra is not None and tex_size == 2048:
         steel.setRoughnessTexture(Texture(ra["sword_roughness"]))
         steel.setMetalTexture(Texture(ra["sword_metallic"]))

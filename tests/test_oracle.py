@@ -206,3 +206,13 @@ def test_flat_quad_is_invisible_and_degenerate_uv_gives_nan_normal():
     sc = Scene(); sc.addToScene("s", MeshObject([(mesh, 0)], [m]))
     fb, ids, _ = orc.render(sc.flatten(), cam, st)
     assert (ids[8, 8, 0] == 0)
+
+
+def test_aimed_camera_rays_hit_collinear_triangles_far_from_the_ray():
+    """The scene of tests/thin_scene.py has teeth: per the oracle (reference semantics, brute force) several of its aimed
+    pixels see a collinear triangle at a distance outside the stretch of the ray that the triangle's bounding box holds
+    (GPURaytracer.cu:586-625: three edge functions of rounding noise weigh the vertex depths), the case the GPU test
+    test_camera_rays_aimed_at_collinear_triangles checks the BVH pipelines on."""
+    import thin_scene
+    sc, cam, st, aimed = thin_scene.aimed_scene(5)
+    assert len(thin_scene.beyond_any_box(sc, cam, st, aimed)) >= 5

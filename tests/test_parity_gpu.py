@@ -171,6 +171,24 @@ def test_live_scene_sequence_soak(ctx):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("seed", [5, 6])
+def test_camera_rays_aimed_at_collinear_triangles(ctx, seed):
+    """Primary-hit parity on collinear triangles by construction (tests/thin_scene.py): anti-aliasing off, and for 195 pixels an
+    object placed so that the line its collinear triangles lie on passes through the pixel's ray at a vertex -- needles (84
+    overlapping triangles on one axis, ordinary rigid instances) and instances of the reference's sword (ten such triangles).
+    Per the oracle several of those pixels see a sliver at a distance that lies outside the stretch of the ray the sliver's
+    own bounding box holds, which a walk of the BVH has no reason to reach: wf_gen / path_kernel test every camera ray
+    against the listed lines and send such samples to the exact walks."""
+    import thin_scene
+    sc, cam, st, aimed = thin_scene.aimed_scene(seed)
+    flat = sc.flatten()
+    assert len(thin_scene.beyond_any_box(sc, cam, st, aimed)) >= 5
+    compare_modes(ctx, flat, cam, st)
+    # ... and with anti-aliasing on (rays that pass the lines by a jitter's width), several samples
+    st.antiAliasingEnabled = True; st.sampleCount = 3
+    compare_modes(ctx, flat, cam, st)
+
+
 def random_rays(rng, n, extent=4.0):
     o = rng.uniform(-extent * 2, extent * 2, (n, 3)).astype(np.float32)
     tgt = rng.uniform(-extent, extent, (n, 3)).astype(np.float32)
@@ -580,11 +598,14 @@ def test_reference_geometry_at_full_size(ctx, name, crop):
 
 def test_config5_progressive_accumulation_at_full_size(ctx):
     """BASELINE.json configs[4] as stated: the full stress scene (9 999 392-triangle terrain + 10 000 spheres =
-    13.5 M triangles, 10 001 objects) at 7680x4320, accumulated over 8 progressive frames of 1 spp
-    (progressiveFrameCount 0..7, GPURaytracer.cu:129-134).  Checked: the oracle's running mean on a crop of the
-    ACCUMULATED buffer, bit for bit; determinism of the whole sequence; interleaved bands compose a frame; and the
-    multi-GPU split (multigpu.frame_indices: each rank sums its own clamped frames, sums added, divided once)
-    against the running mean within 1e-6."""
+    13.5 M triangles, 10 001 objects) at 7680x4320, 256 samples per pixel as 256 progressive frames of 1 spp
+    (progressiveFrameCount 0..255, GPURaytracer.cu:129-134).  Checked: the oracle's running mean over all 256 frames on a
+    crop of the ACCUMULATED buffer, bit for bit; determinism of the whole sequence; interleaved bands compose a frame;
+    and the multi-GPU split (multigpu.frame_indices: each rank sums its own clamped frames, sums added, divided once)
+    against the running mean.  Bound of that last comparison: the running mean r' = (c + r n) / (n + 1) commits three
+    roundings of a value <= 1 per frame, each damped by n / (n + 1) from then on, which leaves e_N = (1 / N) sum k d_k
+    <= N / 2 x 1.8e-7 = 2.3e-5 after N = 256 frames (a third of that in the mean); the sum of 128 clamped frames per
+    rank is exact to an ulp of 128 (1.5e-5) per addition before the division by 256.  Stated: 2e-5; measured: about 2e-6."""
     import torch
     from raytracer_amd import multigpu
     scene, cam, st = scenes.config5()
@@ -599,7 +620,7 @@ def test_config5_progressive_accumulation_at_full_size(ctx):
     run = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)     # running mean, as the reference keeps it
     one = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)     # single frames
     fb_run, fb_one = ctx.framebuffer_wrap(run.data_ptr(), W, H), ctx.framebuffer_wrap(one.data_ptr(), W, H)
-    frames, world = 8, 2
+    frames, world = 256, 2
     sums = [torch.zeros((H, W, 4), dtype=torch.float32, device=dev) for _ in range(world)]
     owner = {f: r for r in range(world) for f in multigpu.frame_indices(0, frames, r, world)}
     rays = []
@@ -613,21 +634,30 @@ def test_config5_progressive_accumulation_at_full_size(ctx):
         sums[owner[k]] += one
     torch.cuda.synchronize()
     split_mean = (sums[0] + sums[1]) / frames
-    assert float((split_mean[..., :3] - run[..., :3]).abs().max()) < 1e-6
+    split_err = float((split_mean[..., :3] - run[..., :3]).abs().max())
+    assert split_err < 2e-5, split_err
     first = run.clone()
-    # the oracle on a crop of the accumulated buffer (brute force over 13.5 M triangles: a small crop)
-    x0, y0, x1, y1 = crop = (5070, 211, 5078, 219)   # straddles the silhouette of sphere 2884 against the terrain
-    acc = None
+    del sums, split_mean
+    # the oracle over the same 256 frames on a crop of the accumulated buffer (brute force over 13.5 M triangles per
+    # segment: one column of 16 pixels, a row per thread), rendered in place
+    x0, y0, x1, y1 = crop = (5074, 207, 5075, 223)   # crosses the silhouette of sphere 2884 against the terrain
+    osc = orc.OracleScene(flat)
+    acc = np.zeros((H, W, 4), np.float32)
+    rid = np.full((H, W, 4), 0xFFFFFFFF, np.uint32)
     for k in range(frames):
         st.frameCount, st.progressiveFrameCount = k, k
-        acc, rid, _ = orc.render(flat, cam, st, rect=crop, prev=acc)
+        orc.render(osc, cam, st, rect=crop, out=acc, ids_out=rid)
     got = run[y0:y1, x0:x1].cpu().numpy()
-    assert np.array_equal(got, acc[y0:y1, x0:x1]) and (rid[y0:y1, x0:x1, 0] != 0xFFFFFFFF).any()
+    assert np.array_equal(got, acc[y0:y1, x0:x1])
+    prim = rid[y0:y1, x0:x1, 0]
+    assert (prim != 0xFFFFFFFF).any() and len(np.unique(prim)) >= 2
+    del acc, rid, osc
     # determinism: the whole sequence again
     for k in range(frames):
         st.frameCount, st.progressiveFrameCount = k, k
         ctx.render(cam, st, fb_run)
-        assert ctx.stats().rays == rays[k]
+        if k % 16 == 0:
+            assert ctx.stats().rays == rays[k]
     ctx.sync()
     assert torch.equal(run, first)
     # one frame as the interleaved bands of three ranks

@@ -101,8 +101,10 @@ def test_reference_textures_decode_like_the_references_own_stb_image():
     fx = os.path.join(ROOT, "tests", "golden", "ref_assets.npz")
     if os.path.exists(fx):
         z = np.load(fx)
-        for key, rel in (("sword_roughness", "pbrsword/texture/Material.002_Roughness.png"), ("metal_metalness", "metalmaterial/Metal046B_1K-PNG_Metalness.png")):
+        for key, rel in (("sword_roughness", "pbrsword/texture/Material.002_Roughness.png"), ("metal_metalness", "metalmaterial/Metal046B_1K-PNG_Metalness.png"),
+                         ("airplane_albedo", "basiclowpoly/Airplane Texture.png"), ("sword_base_color", "pbrsword/texture/Material.002_Base_Color.png")):
             assert np.array_equal(expand_to_rgba8(z[key]), Texture(REF_RES + "/" + rel).rgba8)
+            assert np.array_equal(z[key].reshape(stb_load(REF_RES + "/" + rel).shape), stb_load(REF_RES + "/" + rel))   # C2's and C3's colour maps = the reference's stbi_load bytes
 
 
 @pytest.mark.skipif(not os.path.exists(STB), reason="needs `make -C oracle ref` (the reference checkout)")

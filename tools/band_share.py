@@ -1,22 +1,46 @@
 """One rank's share of the C4 tile split on one GPU: time of rt_render_bands(16, r, N) for N = 1, 2, 4, 8 against frame / N
-(what the strong-scaling curve can be at best, the exchange aside)."""
+(what the strong-scaling curve can be at best, the exchange aside) -- one call after the other on one stream ("serial"), and
+with two frames in flight on two lanes and two streams (RT_OPT_WF_LANE, "2 in flight": what bench.py's tiles mode does).
+   python tools/band_share.py [N] [workload]"""
 import sys, time
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch; torch.cuda.is_available()
 from raytracer_amd import capi, scenes, multigpu
-sc, cam, st = scenes.config4()
+sc, cam, st = getattr(scenes, "config" + (sys.argv[2][1:] if len(sys.argv) > 2 else "4"))()
 ctx = capi.Context(0)
 ctx.upload_scene(sc.flatten())
 ctx.set_camera_rays(cam.preTransformRays)
-fb = ctx.framebuffer(cam.width, cam.height)
+fbs = [ctx.framebuffer(cam.width, cam.height) for _ in range(2)]
 if os.environ.get('WF_CHUNK'): ctx.set_option(capi.OPT_WF_CHUNK, int(os.environ['WF_CHUNK'])); ctx.set_option(capi.OPT_WF_LANES, int(os.environ.get('WF_LANES', '0')))
-base = None
-for n in ([int(sys.argv[1])] if len(sys.argv) > 1 else (1, 2, 4, 8)):
+main = torch.cuda.Stream()
+lanes = [torch.cuda.Stream(), torch.cuda.Stream()]
+REPS = 12
+
+
+def run(n, r, inflight):
+    bands = (multigpu.BAND_ROWS, r, n) if n > 1 else None
+    def frame(i):
+        if inflight == 1:
+            ctx.render(cam, st, fbs[0], bands=bands)
+        else:
+            ctx.set_option(capi.OPT_WF_LANE, i % 2); ctx.set_stream(lanes[i % 2].cuda_stream)
+            ctx.render(cam, st, fbs[i % 2], bands=bands)
+    ctx.set_option(capi.OPT_WF_LANE, 0); ctx.set_stream(main.cuda_stream)
+    for i in range(4): frame(i)
+    torch.cuda.synchronize()
+    ctx.set_option(capi.OPT_WF_LANE, 0); ctx.set_stream(main.cuda_stream)
+    ctx.event_record(0)
+    for s in lanes: s.wait_stream(main)
+    for i in range(REPS): frame(i)
+    for s in lanes: main.wait_stream(s)
+    ctx.set_option(capi.OPT_WF_LANE, 0); ctx.set_stream(main.cuda_stream)
+    ctx.event_record(1); ctx.sync()
+    return ctx.event_elapsed_ms(0, 1) / REPS
+
+
+base = run(1, 0, 1)   # the whole frame, one call after the other
+for n in ([1, int(sys.argv[1])] if len(sys.argv) > 1 and sys.argv[1] != "all" else (1, 2, 4, 8)):
     for r in sorted({0, n - 1}):
-        for _ in range(3): ctx.render(cam, st, fb, bands=(multigpu.BAND_ROWS, r, n) if n > 1 else None)
-        ctx.sync(); ctx.event_record(0)
-        for _ in range(10): ctx.render(cam, st, fb, bands=(multigpu.BAND_ROWS, r, n) if n > 1 else None)
-        ctx.event_record(1); ctx.sync()
-        ms = ctx.event_elapsed_ms(0, 1) / 10
-        base = base or ms
-        print(f"N {n} rank {r}: {ms:.3f} ms   frame / N = {base / n:.3f} ms   efficiency {base / n / ms:.2f}")
+        ms1 = run(n, r, 1)
+        ms2 = run(n, r, 2) if os.environ.get('BS_MODE') != 'serial' else float('nan')   # BS_MODE=serial: tools/band_share_prof.sh reads the last pass
+        print(f"N {n} rank {r}: serial {ms1:.3f} ms (efficiency {base / n / ms1:.2f})   2 in flight {ms2:.3f} ms per frame (efficiency {base / n / ms2:.2f})   frame / N = {base / n:.3f} ms")

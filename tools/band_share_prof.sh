@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf $R/gpurun_out/bs_$1
-timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/bs_$1 -- python3 $R/tools/band_share.py $1 > $R/gpurun_out/bs_$1.log 2>&1
+BS_MODE=serial timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/bs_$1 -- python3 $R/tools/band_share.py $1 > $R/gpurun_out/bs_$1.log 2>&1
 python3 - <<PY
 import csv,glob
 t=glob.glob("$R/gpurun_out/bs_$1/*/*_kernel_trace.csv")[0]
