@@ -59,13 +59,13 @@ class Stats(C.Structure):
 EXPORTS = [
     "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_set_stream", "rt_set_option", "rt_sync", "rt_get_stats",
     "rt_mesh_create", "rt_mesh_destroy", "rt_texture_create", "rt_texture_destroy", "rt_material_create",
-    "rt_material_update", "rt_material_destroy", "rt_object_create", "rt_object_destroy", "rt_scene_commit",
+    "rt_material_update", "rt_material_destroy", "rt_object_create", "rt_object_destroy", "rt_scene_commit", "rt_scene_commit_kind",
     "rt_camera_set_rays", "rt_framebuffer_create", "rt_framebuffer_wrap", "rt_framebuffer_destroy",
     "rt_framebuffer_read", "rt_framebuffer_write", "rt_present", "rt_srgb8_thresholds", "rt_framebuffer_enable_ids", "rt_framebuffer_read_ids",
     "rt_image_load", "rt_image_free", "rt_render", "rt_render_bands", "rt_render_noalloc", "rt_trace_rays", "rt_event_record", "rt_event_elapsed_ms", "rt_detmath_eval", "rt_version",
 ]
 
-OPT_TRAVERSAL, OPT_COUNTERS, OPT_ACCUMULATE_STATS, OPT_WF_CHUNK, OPT_WF_LANES, OPT_BUILDER, OPT_WF_LANE = 1, 2, 3, 4, 5, 6, 7
+OPT_TRAVERSAL, OPT_COUNTERS, OPT_ACCUMULATE_STATS, OPT_WF_CHUNK, OPT_WF_LANES, OPT_BUILDER, OPT_WF_LANE, OPT_REFIT = 1, 2, 3, 4, 5, 6, 7, 8
 
 
 def lib():
@@ -97,6 +97,7 @@ def lib():
                                        C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
         L.rt_object_destroy.argtypes = [C.c_void_p, C.c_int32]
         L.rt_scene_commit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        L.rt_scene_commit_kind.argtypes = [C.c_void_p]
         L.rt_camera_set_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         L.rt_framebuffer_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
         L.rt_framebuffer_wrap.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
@@ -223,6 +224,10 @@ class Context:
         self.check(self.L.rt_scene_commit(self.h, _ptr(oid) if n else None, _ptr(mm) if n else None,
                                           _ptr(im) if n else None, n))
 
+    def commit_kind(self):
+        """1 = the last commit built the acceleration structure, 2 = it refitted the previous one."""
+        return int(self.L.rt_scene_commit_kind(self.h))
+
     def release_scene(self):
         ids = self._scene_handles
         if not ids:
@@ -335,6 +340,8 @@ class GPURaytracer:
         self._key = None
         self._mat_keys = []
         self._keep = None
+        self._ids = None         # the handles of this raytracer's own upload
+        self._xform_key = None   # the matrices of the last commit
 
     def setBounceCount(self, n): self.st.bounceCount = int(n)
     def setMaxDistance(self, d): self.st.maxDistance = float(d)
@@ -358,9 +365,10 @@ class GPURaytracer:
     def raytrace(self, scene: Scene, camera: Camera, fb, rect=None):
         """GPURaytracer::raytrace (GPURaytracer.cu:24-74).  The reference rebuilds its instance table from
         the live objects on every call (Scene.cpp:3-29), so edits to the Scene between two calls show in the
-        next frame.  Here the scene is flattened on every call too; when only transforms and material values
-        changed, the meshes and textures already on the device are kept and the scene is re-committed on
-        their handles (rt_scene_commit + rt_material_update), otherwise everything is uploaded again."""
+        next frame.  Here the scene is flattened on every call too (host work only); when nothing changed, nothing
+        is sent; when only transforms and material values changed, the meshes and textures already on the device
+        are kept, changed materials are patched (rt_material_update) and moved objects re-committed on their handles
+        (rt_scene_commit, which refits the acceleration structure); otherwise everything is uploaded again."""
         self.commit_scene(scene)
         camera.update()
         self.ctx.set_camera_rays(camera.preTransformRays)
@@ -389,17 +397,23 @@ class GPURaytracer:
         flat = scene.flatten()
         key = self._structure(flat)
         ids = self.ctx._scene_handles
-        if self._scene is scene and ids and key == self._key:
+        # the fast paths use the handles of THIS raytracer's own upload: another GPURaytracer, or a direct
+        # ctx.upload_scene(), may have replaced the context's scene since
+        if self._scene is scene and ids is not None and ids is self._ids and key == self._key and len(ids["obj"]) == len(flat.objects):
             for k, m in enumerate(flat.materials):
                 mk = self._material_key(m)
                 if mk != self._mat_keys[k]:
                     self.ctx.update_material(ids["mat"][k], m, ids["tex"])
                     self._mat_keys[k] = mk
-            self.ctx.commit(ids["obj"], [np.asarray(o["model"], np.float32) for o in flat.objects],
-                            [np.asarray(o["invModel"], np.float32) for o in flat.objects])
+            models = [np.asarray(o["model"], np.float32) for o in flat.objects]
+            xkey = b"".join(m.tobytes() for m in models)
+            if xkey != self._xform_key:   # nothing moved: the committed scene stands (scene->dirty())
+                self.ctx.commit(ids["obj"], models, [np.asarray(o["invModel"], np.float32) for o in flat.objects])
+                self._xform_key = xkey
         else:
-            self.ctx.upload_scene(flat)
+            self._ids = self.ctx.upload_scene(flat)
             self._key = key
             self._mat_keys = [self._material_key(m) for m in flat.materials]
+            self._xform_key = b"".join(np.asarray(o["model"], np.float32).tobytes() for o in flat.objects)
             self._keep = flat      # the ids in the key stay unique while these arrays are alive
         self._scene = scene

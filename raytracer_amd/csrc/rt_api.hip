@@ -20,6 +20,10 @@ constexpr size_t kWfChunkDefault = 192u << 20;   // samples; C3 (531 M): 8 chunk
 constexpr size_t kWfChunkFloor = 64u << 20;      // what the default falls back to, by halves, when the workspace does not fit the device
 constexpr int kWfLanesDefault = 3;        // most chunks in flight: the process has 4 hardware queues and one carries the copies, a 4th lane shares a queue and serialises
 constexpr size_t kCntBytes = sizeof(unsigned long long) * rt::kCounterSlots * rt::kCounterStride;
+// A refitted tree whose node boxes sum to more than this times the built tree's area is rebuilt.  Measured on C4 (331 bins
+// jittered independently, tools/refit_probe.py): area x 1.29 -> frame +15 %, x 1.54 -> +18 %, x 1.74 -> +34 %, x 1.93 -> +53 %,
+// against 3.9 ms that a refit (1.6 ms) saves over a build (5.5 ms): past x 1.5 the next frame loses more than the commit won.
+constexpr int kRefitGrowthDefault = 150;   // percent   // a refitted tree whose node boxes sum to more than this times the built tree's area is rebuilt
 
 thread_local std::string g_createError;
 
@@ -66,6 +70,12 @@ struct rt_ctx {
 
     rt::BuiltScene built;
     bool committed = false;
+    // refit bookkeeping: the segment list, mesh epoch and builder of the last FULL build (rt_scene_commit)
+    std::vector<rt::Segment> builtSegs; uint64_t builtEpoch = 0, meshEpoch = 0; int builtBuilder = 0; bool builtValid = false;
+    int commitKind = 0;                       // last rt_scene_commit: 1 = full build, 2 = refit
+    int optRefit = kRefitGrowthDefault;       // 0 = never refit; else the growth limit in percent
+    rt::Segment* dSegs = nullptr; rt::ObjXform* dXf = nullptr;
+    size_t capObjectsBytes = 0, capMaterialsBytes = 0, capSegsBytes = 0, capXfBytes = 0;
     rt::ObjCull* dObjects = nullptr; uint32_t nObjects = 0;
     rt::DevMaterial* dMaterials = nullptr; size_t capMaterials = 0;
     std::vector<rt::DevMaterial> hMaterials;   // host copy of dMaterials: which textures the committed scene can reach
@@ -418,6 +428,7 @@ int rt_ctx_destroy(rt_ctx* c)
     for (auto& t : c->textures) if (t.live) hipFree(t.data);
     for (auto& f : c->fbs) if (f.live) { if (f.owned) hipFree(f.data); hipFree(f.ids); }
     rt::free_scene(c->built);
+    hipFree(c->dSegs); hipFree(c->dXf);
     hipFree(c->dObjects); hipFree(c->dMaterials); hipFree(c->dRays); hipFree(c->dPresent); hipFree(c->dSrgb); hipFree(c->dCounters); hipFree(c->dWork); hipFree(c->dRedoList);
     free_wf(c);
     if (c->hCounters) hipHostFree(c->hCounters);
@@ -455,6 +466,9 @@ int rt_set_option(rt_ctx* c, int option, int value)
     case RT_OPT_WF_LANE:
         if (value < 0 || value >= rt::kWfMaxLanes) return fail(c, RT_ERR_INVALID, "RT_OPT_WF_LANE takes 0 .. 3");
         c->optWfLane = value; return RT_OK;
+    case RT_OPT_REFIT:
+        if (value < 0 || (value > 1 && value <= 100)) return fail(c, RT_ERR_INVALID, "RT_OPT_REFIT takes 0 (off), 1 (default limit) or a growth limit in percent above 100");
+        c->optRefit = value == 1 ? kRefitGrowthDefault : value; return RT_OK;
     case RT_OPT_BUILDER:
         if (value < 0 || value > 1) return fail(c, RT_ERR_INVALID, "RT_OPT_BUILDER takes 0 (PLOC, default) or 1 (radix tree, fast rebuilds)");
         c->optBuilder = value; return RT_OK;
@@ -527,6 +541,7 @@ int rt_mesh_create(rt_ctx* c, const float* pos, int32_t nVerts, const int32_t* i
         return fail(c, RT_ERR_HIP, std::string("mesh upload failed: ") + hipGetErrorString(e));
     }
     m.live = true;
+    c->meshEpoch++;   // a new mesh may sit where a destroyed one sat: the next commit builds, it does not refit
     const rt_id id = alloc_slot(c->meshes);
     c->meshes[id] = m;
     *out = id;
@@ -541,6 +556,7 @@ int rt_mesh_destroy(rt_ctx* c, rt_id id)
     MeshRec& m = c->meshes[id];
     hipFree(m.pos); hipFree(m.idx); hipFree(m.uv); hipFree(m.nrm);
     m = MeshRec();
+    c->meshEpoch++;
     return RT_OK;
 }
 
@@ -684,13 +700,18 @@ int rt_scene_commit(rt_ctx* c, const rt_id* objects, const float* model16, const
     }
     if (total >= (1ull << 28)) return fail(c, RT_ERR_INVALID, "scene exceeds 2^28 triangles");
 
-    // tables (the record arrays and the build's scratch arena in c->built are kept for the re-commit)
+    // tables: kept across commits while they fit (a scene that is re-committed every frame allocates nothing)
     c->committed = false;
-    hipFree(c->dObjects); c->dObjects = nullptr; c->nObjects = 0;
-    hipFree(c->dMaterials); c->dMaterials = nullptr; c->capMaterials = 0;
-
+    auto fit = [&](void** p, size_t& cap, size_t bytes) -> hipError_t {
+        if (bytes <= cap) return hipSuccess;
+        hipFree(*p); *p = nullptr; cap = 0;
+        const hipError_t e = hipMalloc(p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    };
+    c->nObjects = 0;
     if (n > 0) {
-        RT_CHECK(c, hipMalloc((void**)&c->dObjects, sizeof(rt::ObjCull) * (size_t)n));
+        RT_CHECK(c, fit((void**)&c->dObjects, c->capObjectsBytes, sizeof(rt::ObjCull) * (size_t)n));
         RT_CHECK(c, hipMemcpy(c->dObjects, cull.data(), sizeof(rt::ObjCull) * (size_t)n, hipMemcpyHostToDevice));
         c->nObjects = (uint32_t)n;
     }
@@ -701,32 +722,47 @@ int rt_scene_commit(rt_ctx* c, const rt_id* objects, const float* model16, const
             if (c->materials[i].live) mats[i] = to_dev(c->materials[i].desc, c->textures);
             else mats[i].texNormal = mats[i].texAlbedo = mats[i].texRoughness = mats[i].texMetal = -1; // unused slot: binds nothing
         if (c->materials.empty()) mats[0].texNormal = mats[0].texAlbedo = mats[0].texRoughness = mats[0].texMetal = -1;
-        RT_CHECK(c, hipMalloc((void**)&c->dMaterials, sizeof(rt::DevMaterial) * mats.size()));
+        c->capMaterials = 0;
+        RT_CHECK(c, fit((void**)&c->dMaterials, c->capMaterialsBytes, sizeof(rt::DevMaterial) * mats.size()));
         RT_CHECK(c, hipMemcpy(c->dMaterials, mats.data(), sizeof(rt::DevMaterial) * mats.size(), hipMemcpyHostToDevice));
         c->capMaterials = mats.size();
         c->hMaterials = mats;
     }
-
-    rt::Segment* dSegs = nullptr;
-    rt::ObjXform* dXf = nullptr;
     if (!segs.empty()) {
-        RT_CHECK(c, hipMalloc((void**)&dSegs, sizeof(rt::Segment) * segs.size()));
-        RT_CHECK(c, hipMalloc((void**)&dXf, sizeof(rt::ObjXform) * (size_t)n));
-        RT_CHECK(c, hipMemcpy(dSegs, segs.data(), sizeof(rt::Segment) * segs.size(), hipMemcpyHostToDevice));
-        RT_CHECK(c, hipMemcpy(dXf, xf.data(), sizeof(rt::ObjXform) * (size_t)n, hipMemcpyHostToDevice));
+        RT_CHECK(c, fit((void**)&c->dSegs, c->capSegsBytes, sizeof(rt::Segment) * segs.size()));
+        RT_CHECK(c, fit((void**)&c->dXf, c->capXfBytes, sizeof(rt::ObjXform) * (size_t)n));
+        RT_CHECK(c, hipMemcpy(c->dSegs, segs.data(), sizeof(rt::Segment) * segs.size(), hipMemcpyHostToDevice));
+        RT_CHECK(c, hipMemcpy(c->dXf, xf.data(), sizeof(rt::ObjXform) * (size_t)n, hipMemcpyHostToDevice));
     }
     hipEventRecord(c->slots[14], c->stream);
     std::string err;
-    const bool ok = rt::build_scene(dSegs, (int)segs.size(), dXf, (uint32_t)total, c->built, c->optBuilder, c->stream, err);
+    // The dynamic-scene path: the same instances of the same meshes under other matrices (what the reference's per-frame
+    // instance table amounts to, Scene.cpp:3-29) keep the tree of the last full build and refit its boxes; anything else,
+    // or a refitted tree whose boxes have grown past the limit (RT_OPT_REFIT), is built anew.
+    const bool sameStructure = c->optRefit && c->builtValid && c->builtEpoch == c->meshEpoch && c->builtBuilder == c->optBuilder &&
+                               segs.size() == c->builtSegs.size() &&
+                               (segs.empty() || memcmp(segs.data(), c->builtSegs.data(), sizeof(rt::Segment) * segs.size()) == 0);
+    bool ok = false;
+    c->commitKind = 0;
+    if (sameStructure && total > 1) {
+        ok = rt::refit_scene(c->dSegs, (int)segs.size(), c->dXf, (uint32_t)total, c->built, 0.01f * (float)c->optRefit, c->stream, err);
+        if (ok) c->commitKind = 2;
+        else if (!err.empty()) { c->builtValid = false; rt::free_scene(c->built); return fail(c, RT_ERR_HIP, "scene refit failed: " + err); }
+    }
+    if (!ok) {
+        ok = rt::build_scene(c->dSegs, (int)segs.size(), c->dXf, (uint32_t)total, c->built, c->optBuilder, c->stream, err);
+        if (ok) { c->commitKind = 1; c->builtSegs = segs; c->builtEpoch = c->meshEpoch; c->builtBuilder = c->optBuilder; c->builtValid = true; }
+    }
     hipEventRecord(c->slots[15], c->stream);
     hipStreamSynchronize(c->stream);
-    hipFree(dSegs); hipFree(dXf);
-    if (!ok) { rt::free_scene(c->built); return fail(c, RT_ERR_HIP, "scene build failed: " + err); }
+    if (!ok) { c->builtValid = false; rt::free_scene(c->built); return fail(c, RT_ERR_HIP, "scene build failed: " + err); }
     hipEventElapsedTime(&c->commitMs, c->slots[14], c->slots[15]);
     c->bandRel = band_rel_of(model16, invModel16, n);
     c->committed = true;
     return RT_OK;
 }
+
+int rt_scene_commit_kind(const rt_ctx* c) { return c ? c->commitKind : 0; }
 
 int rt_camera_set_rays(rt_ctx* c, const float* rays4, int32_t w, int32_t h)
 {

@@ -3,6 +3,7 @@
 #pragma once
 #include "rt_device.h"
 #include <string>
+#include <vector>
 
 namespace rt {
 
@@ -37,10 +38,25 @@ struct BuiltScene {
     uint32_t capTris = 0;
     void* arena = nullptr;
     size_t arenaBytes = 0;
+    // what a refit needs of the last full build (refit_scene): the four-wide nodes of level L are levelBegin[L] ..
+    // levelBegin[L + 1] - 1 (the collapse allocates them level by level), places in the arena, and the summed surface
+    // area of the node boxes the build ended with
+    std::vector<uint32_t> levelBegin;
+    uint32_t* sBounds = nullptr; uint32_t* sThinCount = nullptr; ThinTri* sThinTmp = nullptr; float* sBoxes = nullptr; float* sArea = nullptr;
+    float buildArea = 0.0f;
+    float lastArea = 0.0f;          // ... and the area after the last build or refit
 };
 
 // builder: 0 = PLOC (quality), 1 = Karras radix tree (fast rebuilds)
 bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t nTris, BuiltScene& out, int builder,
+                 hipStream_t stream, std::string& err);
+// The dynamic-scene path (the reference's per-frame cost for a moved object is one glm::inverse and a
+// 136-byte copy, Scene.cpp:3-29): the same instances and meshes under other matrices.  Flattens again, keeps the topology
+// of the four-wide tree and fits its boxes bottom up, one launch per level; no Morton codes, no sort, no clustering, no
+// collapse.  Returns false with err empty when the tree cannot be refitted (never built, a single triangle) or has
+// degraded -- the summed area of the node boxes exceeds maxGrowth times that of the last full build -- and the caller
+// rebuilds.  Any tree over the same triangles gives the same pixels: only the frame time depends on this choice.
+bool refit_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t nTris, BuiltScene& out, float maxGrowth,
                  hipStream_t stream, std::string& err);
 void free_scene(BuiltScene& s);
 

@@ -359,6 +359,27 @@ __device__ __forceinline__ const float* box_of(int c, const float* __restrict__ 
     return boxes + 6 * (size_t)(c < 0 ? nLeaves - 1 + (~c) : c);
 }
 
+// scale of a node along one axis: the smallest power of two with extent / scale <= 250 (five steps of slack for the
+// outward rounding of the child planes)
+__device__ __forceinline__ float node_scale(float ext)
+{
+    int e;
+    const float m = frexpf(ext * (1.0f / 250.0f), &e);   // ext/250 = m * 2^e, m in [0.5, 1)
+    e = (ext > 0.0f) ? (m == 0.5f ? e - 1 : e) : -120;
+    if (e < -120) e = -120;
+    return ldexpf(1.0f, e);
+}
+// child planes as 8-bit offsets from the node's origin, lower planes rounded down, upper planes rounded up
+__device__ __forceinline__ void quantise_planes(float lo, float hi, float origin, float sc, int& q0, int& q1)
+{
+    q0 = (int)floorf((lo - origin) / sc);
+    q0 = q0 < 0 ? 0 : (q0 > 255 ? 255 : q0);
+    while (q0 > 0 && origin + (float)q0 * sc > lo) q0--;
+    q1 = (int)ceilf((hi - origin) / sc);
+    q1 = q1 < 0 ? 0 : (q1 > 255 ? 255 : q1);
+    while (q1 < 255 && origin + (float)q1 * sc < hi) q1++;
+}
+
 __global__ __launch_bounds__(256) void collapse_kernel(const int2* __restrict__ children, const int* __restrict__ count,
                                                        const float* __restrict__ boxes, int nLeaves,
                                                        const int2* __restrict__ qIn, const uint32_t* __restrict__ firstIn, uint32_t qCount,
@@ -420,15 +441,7 @@ __global__ __launch_bounds__(256) void collapse_kernel(const int2* __restrict__ 
     nd.ox = nlo[0]; nd.oy = nlo[1]; nd.oz = nlo[2];
     float sc[3];
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
-        // smallest power of two with extent / scale <= 250 (five steps of slack for the outward rounding below)
-        const float ext = nhi[a] - nlo[a];
-        int e;
-        const float m = frexpf(ext * (1.0f / 250.0f), &e);   // ext/250 = m * 2^e, m in [0.5, 1)
-        e = (ext > 0.0f) ? (m == 0.5f ? e - 1 : e) : -120;
-        if (e < -120) e = -120;
-        sc[a] = ldexpf(1.0f, e);
-    }
+    for (int a = 0; a < 3; a++) sc[a] = node_scale(nhi[a] - nlo[a]);
     nd.sx = sc[0]; nd.sy = sc[1]; nd.sz = sc[2];
     uint32_t ql[3] = { 0, 0, 0 }, qh[3] = { 0, 0, 0 };
     int j = 0;
@@ -438,12 +451,8 @@ __global__ __launch_bounds__(256) void collapse_kernel(const int2* __restrict__ 
             const int c = cs[k];
 #pragma unroll
             for (int a = 0; a < 3; a++) {
-                int q0 = (int)floorf((lo[k][a] - nlo[a]) / sc[a]);
-                q0 = q0 < 0 ? 0 : (q0 > 255 ? 255 : q0);
-                while (q0 > 0 && nlo[a] + (float)q0 * sc[a] > lo[k][a]) q0--;
-                int q1 = (int)ceilf((hi[k][a] - nlo[a]) / sc[a]);
-                q1 = q1 < 0 ? 0 : (q1 > 255 ? 255 : q1);
-                while (q1 < 255 && nlo[a] + (float)q1 * sc[a] < hi[k][a]) q1++;
+                int q0, q1;
+                quantise_planes(lo[k][a], hi[k][a], nlo[a], sc[a], q0, q1);
                 ql[a] |= (uint32_t)q0 << (8 * k);
                 qh[a] |= (uint32_t)q1 << (8 * k);
             }
@@ -607,6 +616,113 @@ __global__ __launch_bounds__(256) void ploc_merge_kernel(const int* __restrict__
     out[(uint32_t)pre] = c;
 }
 
+// ---- refit: the tree's topology stays, its boxes follow the triangles (refit_scene) ----
+// the leaf-order copies again: slot d keeps its triangle (the unrotated copy names it), whose record has moved
+__global__ __launch_bounds__(256) void regather_kernel(const TriIsect* __restrict__ triRef, uint32_t nTris, TriIsect* __restrict__ triLeaf)
+{
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= nTris) return;
+    const TriIsect t = triRef[triLeaf[2 * (size_t)nTris + d].gid];
+    TriIsect r = t;
+    r.v0x = t.v0y; r.v0y = t.v0z; r.v0z = t.v0x; r.v1x = t.v1y; r.v1y = t.v1z; r.v1z = t.v1x; r.v2x = t.v2y; r.v2y = t.v2z; r.v2z = t.v2x;
+    triLeaf[d] = r;
+    r.v0x = t.v0z; r.v0y = t.v0x; r.v0z = t.v0y; r.v1x = t.v1z; r.v1y = t.v1x; r.v1z = t.v1y; r.v2x = t.v2z; r.v2y = t.v2x; r.v2z = t.v2y;
+    triLeaf[(size_t)nTris + d] = r;
+    triLeaf[2 * (size_t)nTris + d] = t;
+}
+
+// One level of the four-wide tree, deepest first: a node's child boxes come from the triangles of its leaves and from
+// the boxes the level below has just written (float boxes kept beside the nodes for the duration: fitting from the decoded
+// 8-bit planes would widen every level by its rounding), then the node is encoded as the collapse encodes it.
+__global__ __launch_bounds__(256) void refit_level_kernel(BvhNode* __restrict__ nodes, float* __restrict__ nodeBox,
+                                                          const TriIsect* __restrict__ triWorld, uint32_t begin, uint32_t end)
+{
+    const uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= end) return;
+    BvhNode nd = nodes[i];
+    const float kBig = 1e30f;
+    float lo[4][3], hi[4][3];
+    bool used[4];
+    float nlo[3] = { kBig, kBig, kBig }, nhi[3] = { -kBig, -kBig, -kBig };
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int32_t c = nd.child[k];
+        float b[6];
+        used[k] = true;
+        if (c >= 0) {
+#pragma unroll
+            for (int a = 0; a < 6; a++) b[a] = nodeBox[6 * (size_t)c + a];
+        } else {
+            const uint32_t code = (uint32_t)(~c), first = code >> 3, cnt = code & 7u;
+            used[k] = cnt != 0u;
+            b[0] = b[1] = b[2] = FLT_MAX; b[3] = b[4] = b[5] = -FLT_MAX;
+            for (uint32_t t = 0; t < cnt; t++) {
+                float mn[3], mx[3];
+                tri_box(triWorld[first + t], mn, mx);
+#pragma unroll
+                for (int a = 0; a < 3; a++) { b[a] = __builtin_fminf(b[a], mn[a]); b[3 + a] = __builtin_fmaxf(b[3 + a], mx[a]); }
+            }
+        }
+        if (!used[k]) continue;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            lo[k][a] = __builtin_fminf(__builtin_fmaxf(b[a], -kBig), kBig);       // NaN -> -kBig / +kBig: covers everything
+            hi[k][a] = __builtin_fmaxf(__builtin_fminf(b[3 + a], kBig), -kBig);
+            nlo[a] = __builtin_fminf(nlo[a], lo[k][a]);
+            nhi[a] = __builtin_fmaxf(nhi[a], hi[k][a]);
+        }
+    }
+    float sc[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) { sc[a] = node_scale(nhi[a] - nlo[a]); nodeBox[6 * (size_t)i + a] = nlo[a]; nodeBox[6 * (size_t)i + 3 + a] = nhi[a]; }
+    nd.ox = nlo[0]; nd.oy = nlo[1]; nd.oz = nlo[2];
+    nd.sx = sc[0]; nd.sy = sc[1]; nd.sz = sc[2];
+    uint32_t ql[3] = { 0, 0, 0 }, qh[3] = { 0, 0, 0 };
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (used[k]) {
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                int q0, q1;
+                quantise_planes(lo[k][a], hi[k][a], nlo[a], sc[a], q0, q1);
+                ql[a] |= (uint32_t)q0 << (8 * k);
+                qh[a] |= (uint32_t)q1 << (8 * k);
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; a++) ql[a] |= 255u << (8 * k);   // unused slot: inverted box
+        }
+    }
+    nd.lox = ql[0]; nd.loy = ql[1]; nd.loz = ql[2];
+    nd.hix = qh[0]; nd.hiy = qh[1]; nd.hiz = qh[2];
+    nodes[i] = nd;
+}
+
+// summed surface area of the node boxes (as encoded), the measure of how far a refitted tree has degraded
+__global__ __launch_bounds__(256) void node_area_kernel(const BvhNode* __restrict__ nodes, uint32_t nNodes, float* __restrict__ acc)
+{
+    float sum = 0.0f;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nNodes; i += gridDim.x * blockDim.x) {
+        const BvhNode nd = nodes[i];
+        uint32_t lo[3] = { 255u, 255u, 255u }, hi[3] = { 0u, 0u, 0u };
+        const uint32_t ql[3] = { nd.lox, nd.loy, nd.loz }, qh[3] = { nd.hix, nd.hiy, nd.hiz };
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const uint32_t l = (ql[a] >> (8 * k)) & 255u, h = (qh[a] >> (8 * k)) & 255u;
+                if (l <= h) { lo[a] = l < lo[a] ? l : lo[a]; hi[a] = h > hi[a] ? h : hi[a]; }
+            }
+        const float dx = lo[0] <= hi[0] ? (float)(hi[0] - lo[0]) * nd.sx : 0.0f, dy = lo[1] <= hi[1] ? (float)(hi[1] - lo[1]) * nd.sy : 0.0f,
+                    dz = lo[2] <= hi[2] ? (float)(hi[2] - lo[2]) * nd.sz : 0.0f;
+        const float A = dx * dy + dy * dz + dz * dx;
+        if (A < 1e30f) sum += A;   // boxes blown up by non-finite vertices count for nothing
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if ((threadIdx.x & 63) == 0 && sum != 0.0f) atomicAdd(acc, sum);
+}
+
 #define RT_HIP(call)                                                                                         \
     do {                                                                                                     \
         hipError_t e_ = (call);                                                                              \
@@ -626,6 +742,8 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
     out.nNodes = 0;
     out.sceneMaxAbs = 0.0f;
     out.nThin = 0;
+    out.levelBegin.clear();
+    out.buildArea = out.lastArea = 0.0f;
     if (nTris == 0) return true;
     const uint32_t grid = (nTris + 255) / 256;
     const uint32_t nInternal = nTris > 1 ? nTris - 1 : 1;
@@ -670,7 +788,7 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
         const size_t oBounds = take(6 * sizeof(uint32_t)), oKeysA = take(8 * n), oKeysB = take(8 * n), oValsA = take(4 * n),
                      oValsB = take(4 * n), oSort = take(tmpBytes ? tmpBytes : 16), oBoxes = take(sizeof(float) * 6 * 2 * n),
                      oChildren = take(sizeof(int2) * ni), oCount = take(sizeof(int) * ni), oDone = take(4 * ni),
-                     oRemaining = take(4), oThinCount = take(4), oThin = take(sizeof(ThinTri) * n), oParent = take(sizeof(int) * (2 * n)), oQueueA = take(sizeof(int2) * ni), oQueueB = take(sizeof(int2) * ni);
+                     oRemaining = take(4), oThinCount = take(4), oArea = take(4), oThin = take(sizeof(ThinTri) * n), oParent = take(sizeof(int) * (2 * n)), oQueueA = take(sizeof(int2) * ni), oQueueB = take(sizeof(int2) * ni);
         if (off > out.arenaBytes) {
             hipFree(out.arena); out.arena = nullptr; out.arenaBytes = 0;
             RT_HIP(hipMalloc(&out.arena, off));
@@ -682,6 +800,7 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
         children = (int2*)(base + oChildren); count = (int*)(base + oCount); done = (uint32_t*)(base + oDone);
         thinCount = (uint32_t*)(base + oThinCount); thinTmp = (ThinTri*)(base + oThin);
         remaining = (uint32_t*)(base + oRemaining); parent = (int*)(base + oParent); queueA = (int2*)(base + oQueueA); queueB = (int2*)(base + oQueueB);
+        out.sBounds = dBounds; out.sThinCount = thinCount; out.sThinTmp = thinTmp; out.sBoxes = boxes; out.sArea = (float*)(base + oArea);
     }
 
     const uint32_t hb[6] = { host_f2o(FLT_MAX), host_f2o(FLT_MAX), host_f2o(FLT_MAX),
@@ -834,14 +953,18 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
     RT_HIPC(hipMemcpyAsync(done, &one, sizeof(one), hipMemcpyHostToDevice, stream));
     uint32_t qCount = 1;
     int depthLevels = 0;
+    out.levelBegin.push_back(0u); out.levelBegin.push_back(1u);   // level 0 is the root; a level's launch allocates the next level's nodes
     for (int level = 0; qCount > 0; level++, depthLevels++) {
         if (level > 4 * kStackDepth) { err = "BVH collapse did not terminate"; cleanup(); return false; }
         RT_HIPC(hipMemsetAsync(remaining, 0, sizeof(uint32_t), stream));
         hipLaunchKernelGGL(collapse_kernel, dim3((qCount + 255) / 256), dim3(256), 0, stream, children, count, boxes,
                            (int)nTris, queueA, firstA, qCount, queueB, firstB, remaining, done, out.nodes, pos);
         RT_HIPC(hipGetLastError());
+        uint32_t allocated = 0;
         RT_HIPC(hipMemcpyAsync(&qCount, remaining, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        RT_HIPC(hipMemcpyAsync(&allocated, done, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         RT_HIPC(hipStreamSynchronize(stream));
+        out.levelBegin.push_back(allocated);
         int2* t = queueA; queueA = queueB; queueB = t;
         uint32_t* tf = firstA; firstA = firstB; firstB = tf;
     }
@@ -858,10 +981,74 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
     uint32_t nNodes = 0;
     RT_HIPC(hipMemcpyAsync(&nNodes, done, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     RT_HIPC(hipStreamSynchronize(stream));
+    // the summed area of the node boxes: what later refits are measured against
+    RT_HIPC(hipMemsetAsync(out.sArea, 0, sizeof(float), stream));
+    hipLaunchKernelGGL(node_area_kernel, dim3(grid < 1024u ? grid : 1024u), dim3(256), 0, stream, out.nodes, nNodes, out.sArea);
+    RT_HIPC(hipGetLastError());
+    RT_HIPC(hipMemcpyAsync(&out.buildArea, out.sArea, sizeof(float), hipMemcpyDeviceToHost, stream));
+    RT_HIPC(hipStreamSynchronize(stream));
     out.nNodes = nNodes;
+    out.lastArea = out.buildArea;
     cleanup();
     return true;
 #undef RT_HIPC
+}
+
+bool refit_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t nTris, BuiltScene& out, float maxGrowth,
+                 hipStream_t stream, std::string& err)
+{
+    err.clear();
+    if (nTris < 2 || nTris != out.nTris || out.levelBegin.size() < 3 || !out.sBoxes || !(out.buildArea > 0.0f)) return false;
+    const uint32_t grid = (nTris + 255) / 256;
+    const uint32_t hb[6] = { host_f2o(FLT_MAX), host_f2o(FLT_MAX), host_f2o(FLT_MAX),
+                             host_f2o(-FLT_MAX), host_f2o(-FLT_MAX), host_f2o(-FLT_MAX) };
+    RT_HIP(hipMemcpyAsync(out.sBounds, hb, sizeof(hb), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(flatten_kernel, dim3(grid < 4096u ? grid : 4096u), dim3(256), 0, stream, dSegs, nSegs, dXf, nTris, out.triRef,
+                       out.triShade, out.sBounds);
+    RT_HIP(hipGetLastError());
+    uint32_t hbOut[6];
+    RT_HIP(hipMemcpyAsync(hbOut, out.sBounds, sizeof(hbOut), hipMemcpyDeviceToHost, stream));
+    RT_HIP(hipStreamSynchronize(stream));
+    float maxAbs = 0.0f;
+    for (int k = 0; k < 6; k++) {
+        const float f = o2f(hbOut[k]);
+        if (f < FLT_MAX && f > -FLT_MAX && fabsf(f) > maxAbs) maxAbs = fabsf(f);
+    }
+    out.sceneMaxAbs = maxAbs;
+    // the triangles no box can stand for, listed again (their lines have moved, and the threshold follows the scene's extent)
+    RT_HIP(hipMemsetAsync(out.sThinCount, 0, 4, stream));
+    hipLaunchKernelGGL(thin_kernel, dim3(grid), dim3(256), 0, stream, out.triRef, nTris, maxAbs * 7.62939453125e-06f, out.sThinCount, out.sThinTmp);
+    RT_HIP(hipGetLastError());
+    // leaf-order copies, then the levels of the tree, deepest first
+    hipLaunchKernelGGL(regather_kernel, dim3(grid), dim3(256), 0, stream, out.triRef, nTris, out.triLeaf);
+    RT_HIP(hipGetLastError());
+    for (size_t L = out.levelBegin.size() - 1; L-- > 0;) {
+        const uint32_t b = out.levelBegin[L], e = out.levelBegin[L + 1];
+        if (e <= b) continue;
+        hipLaunchKernelGGL(refit_level_kernel, dim3((e - b + 255) / 256), dim3(256), 0, stream, out.nodes, out.sBoxes,
+                           out.triLeaf + 2 * (size_t)nTris, b, e);
+    }
+    RT_HIP(hipGetLastError());
+    RT_HIP(hipMemsetAsync(out.sArea, 0, sizeof(float), stream));
+    hipLaunchKernelGGL(node_area_kernel, dim3(grid < 1024u ? grid : 1024u), dim3(256), 0, stream, out.nodes, out.nNodes, out.sArea);
+    RT_HIP(hipGetLastError());
+    uint32_t n = 0;
+    float area = 0.0f;
+    RT_HIP(hipMemcpyAsync(&n, out.sThinCount, 4, hipMemcpyDeviceToHost, stream));
+    RT_HIP(hipMemcpyAsync(&area, out.sArea, sizeof(float), hipMemcpyDeviceToHost, stream));
+    RT_HIP(hipStreamSynchronize(stream));
+    if (n > out.capThin) {
+        hipFree(out.thin); out.thin = nullptr; out.capThin = 0;
+        RT_HIP(hipMalloc((void**)&out.thin, sizeof(ThinTri) * (size_t)n));
+        out.capThin = n;
+    }
+    if (n) RT_HIP(hipMemcpyAsync(out.thin, out.sThinTmp, sizeof(ThinTri) * (size_t)n, hipMemcpyDeviceToDevice, stream));
+    out.nThin = n;
+    out.lastArea = area;
+    RT_HIP(hipStreamSynchronize(stream));
+    if (getenv("RT_AMD_DEBUG_BUILD")) fprintf(stderr, "[rt_amd] refit: node area %.4g, %.3f x the built tree's\n", area, area / out.buildArea);
+    // a tree whose boxes have grown past the limit (objects that have moved through each other) is rebuilt by the caller
+    return area <= maxGrowth * out.buildArea;
 }
 
 void free_scene(BuiltScene& s)

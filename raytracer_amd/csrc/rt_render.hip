@@ -811,8 +811,18 @@ __device__ __forceinline__ bool wf_pixel(const RenderArgs& a, const WfBufs& w, u
         const uint32_t k = row / (uint32_t)a.bandTileRows, in_band = row - k * (uint32_t)a.bandTileRows;
         row = ((uint32_t)a.bandFirst + k * (uint32_t)a.bandStride) * (uint32_t)a.bandTileRows + in_band;
     }
-    x = a.x0 + (int)(tile % (uint32_t)a.tiles8X) * 8 + (int)(in & 7u);
-    y = a.y0 + (int)row * 8 + (int)(in >> 3);
+#ifndef RT_TILE_ORDER
+#define RT_TILE_ORDER 1
+#endif
+#if RT_TILE_ORDER
+    // Z order inside the tile: consecutive pixels form 2x2, 4x4 ... blocks, so the 64 camera rays that walk the tree together
+    // as a packet (16 pixels at 4 spp, 4 at 16) cover a square of the image instead of a strip of a row or two
+    const uint32_t px = (in & 1u) | ((in >> 1) & 2u) | ((in >> 2) & 4u), py = ((in >> 1) & 1u) | ((in >> 2) & 2u) | ((in >> 3) & 4u);
+#else
+    const uint32_t px = in & 7u, py = in >> 3;
+#endif
+    x = a.x0 + (int)(tile % (uint32_t)a.tiles8X) * 8 + (int)px;
+    y = a.y0 + (int)row * 8 + (int)py;
     return x < a.x1 && y < a.y1;
 }
 

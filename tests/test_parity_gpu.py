@@ -696,37 +696,61 @@ def test_custom_model_from_asset_files(ctx, tmp_path):
     assert (rid[..., 0] != 0xFFFFFFFF).mean() > 0.05 and not (rid[..., 0] == 1).any()
 
 
+@pytest.mark.parametrize("refit", [1, 0], ids=["refit", "rebuild"])
 @pytest.mark.parametrize("builder", [0, 1], ids=["ploc", "radix-tree"])
-def test_dynamic_scene_recommit_matches_oracle(ctx, builder):
+def test_dynamic_scene_recommit_matches_oracle(ctx, builder, refit):
     """the reference rebuilds its instance table every frame (Scene.cpp:3-29).  Here the
     transforms are re-committed on the handles already uploaded (no mesh / texture re-upload; the record
-    arrays and the build's scratch arena are reused) and the frame must match the oracle's for the moved scene."""
+    arrays and the build's scratch arena are reused), the acceleration structure of the first commit is refitted
+    (RT_OPT_REFIT, the default) or built again, and the frame must match the oracle's for the moved scene -- also
+    after a move so large that the refitted boxes pass the growth limit and the commit falls back to a build, after a
+    rescale, and in the brute-force and persistent modes on the refitted records."""
     sc, cam = pbr_scene(seed=5, n_obj=12)
     cam.setWidth(128); cam.setHeight(80); cam.calcRays()
     st = RenderSettings(bounceCount=3, sampleCount=2)
     flat = sc.flatten()
     ctx.set_option(capi.OPT_TRAVERSAL, 0)
     ctx.set_option(capi.OPT_BUILDER, builder)   # 1: the builder meant for scenes re-committed every frame
-    ids = ctx.upload_scene(flat)
-    ctx.set_camera_rays(cam.preTransformRays)
-    fb = ctx.framebuffer(cam.width, cam.height, ids=True)
-    first_ms = ctx.stats().commit_ms
-    for step in range(3):
-        for k, (name, obj) in enumerate(sc.getObjects().items()):
-            p = np.asarray(obj.Position, np.float32)
-            obj.setPosition((float(p[0]) + 0.07 * (k % 3 - 1), float(p[1]) + 0.05 * step, float(p[2]) - 0.04 * k))
-        flat = sc.flatten()
-        ctx.commit(ids["obj"], [np.asarray(o["model"], np.float32) for o in flat.objects],
-                   [np.asarray(o["invModel"], np.float32) for o in flat.objects])
-        st.frameCount = step
-        ctx.render(cam, st, fb)
-        img, gid, stats = ctx.read(fb, cam.width, cam.height), ctx.read_ids(fb, cam.width, cam.height), ctx.stats()
-        ref, rid, nq = orc.render(flat, cam, st)
-        check(ref, rid, nq, img, gid, stats)
-        assert np.array_equal(img, ref)
-    print("commit ms: first %.2f, re-commit %.2f" % (first_ms, ctx.stats().commit_ms))
-    ctx.framebuffer_destroy(fb)
-    ctx.set_option(capi.OPT_BUILDER, 0)
+    ctx.set_option(capi.OPT_REFIT, refit)
+    try:
+        ids = ctx.upload_scene(flat)
+        assert ctx.commit_kind() == 1
+        ctx.set_camera_rays(cam.preTransformRays)
+        fb = ctx.framebuffer(cam.width, cam.height, ids=True)
+        first_ms = ctx.stats().commit_ms
+        kinds = []
+        for step in range(5):
+            for k, (name, obj) in enumerate(sc.getObjects().items()):
+                p = np.asarray(obj.Position, np.float32)
+                if step < 3:
+                    obj.setPosition((float(p[0]) + 0.07 * (k % 3 - 1), float(p[1]) + 0.05 * step, float(p[2]) - 0.04 * k))
+                elif step == 3:   # scattered far and wide: the tree of the first commit no longer fits
+                    obj.setPosition((float(p[0]) * 9.0 + 3.0 * (k % 5), float(p[1]) * 7.0, float(p[2]) * 9.0 - 40.0 * (k % 2)))
+                else:             # ... and gathered again, at other sizes
+                    obj.setPosition((float(p[0]) / 9.0, float(p[1]) / 7.0, float(p[2]) / 30.0))
+                    obj.setScale(tuple(np.asarray(obj.Scale, np.float32) * (0.6 + 0.1 * (k % 4))))
+            flat = sc.flatten()
+            ctx.commit(ids["obj"], [np.asarray(o["model"], np.float32) for o in flat.objects],
+                       [np.asarray(o["invModel"], np.float32) for o in flat.objects])
+            kinds.append(ctx.commit_kind())
+            st.frameCount = step
+            ref, rid, nq = orc.render(flat, cam, st)
+            for mode in (0, 2, 1) if step in (1, 4) else (0,):
+                ctx.set_option(capi.OPT_TRAVERSAL, mode)
+                ctx.render(cam, st, fb)
+                img, gid, stats = ctx.read(fb, cam.width, cam.height), ctx.read_ids(fb, cam.width, cam.height), ctx.stats()
+                check(ref, rid, nq, img, gid, stats)
+                assert np.array_equal(img, ref)
+            ctx.set_option(capi.OPT_TRAVERSAL, 0)
+        print("commit ms: first %.2f, re-commit %.2f; kinds %s" % (first_ms, ctx.stats().commit_ms, kinds))
+        if refit:
+            assert kinds[:3] == [2, 2, 2] and 1 in kinds[3:], kinds   # small moves refit; the scatter rebuilds
+        else:
+            assert kinds == [1] * 5, kinds
+        ctx.framebuffer_destroy(fb)
+    finally:
+        ctx.set_option(capi.OPT_BUILDER, 0)
+        ctx.set_option(capi.OPT_REFIT, 1)
 
 
 @pytest.mark.parametrize("lanes,chunk", [(1, 1024), (3, 2048), (4, 1 << 20)])

@@ -10,11 +10,11 @@ sc, cam, st = getattr(scenes, "config" + (sys.argv[2][1:] if len(sys.argv) > 2 e
 ctx = capi.Context(0)
 ctx.upload_scene(sc.flatten())
 ctx.set_camera_rays(cam.preTransformRays)
-fbs = [ctx.framebuffer(cam.width, cam.height) for _ in range(2)]
+fbs = [ctx.framebuffer(cam.width, cam.height) for _ in range(4)]
 if os.environ.get('WF_CHUNK'): ctx.set_option(capi.OPT_WF_CHUNK, int(os.environ['WF_CHUNK'])); ctx.set_option(capi.OPT_WF_LANES, int(os.environ.get('WF_LANES', '0')))
 main = torch.cuda.Stream()
-lanes = [torch.cuda.Stream(), torch.cuda.Stream()]
-REPS = 12
+lanes = [torch.cuda.Stream() for _ in range(4)]
+REPS = 24
 
 
 def run(n, r, inflight):
@@ -23,8 +23,8 @@ def run(n, r, inflight):
         if inflight == 1:
             ctx.render(cam, st, fbs[0], bands=bands)
         else:
-            ctx.set_option(capi.OPT_WF_LANE, i % 2); ctx.set_stream(lanes[i % 2].cuda_stream)
-            ctx.render(cam, st, fbs[i % 2], bands=bands)
+            ctx.set_option(capi.OPT_WF_LANE, i % inflight); ctx.set_stream(lanes[i % inflight].cuda_stream)
+            ctx.render(cam, st, fbs[i % inflight], bands=bands)
     ctx.set_option(capi.OPT_WF_LANE, 0); ctx.set_stream(main.cuda_stream)
     for i in range(4): frame(i)
     torch.cuda.synchronize()
@@ -42,5 +42,9 @@ base = run(1, 0, 1)   # the whole frame, one call after the other
 for n in ([1, int(sys.argv[1])] if len(sys.argv) > 1 and sys.argv[1] != "all" else (1, 2, 4, 8)):
     for r in sorted({0, n - 1}):
         ms1 = run(n, r, 1)
-        ms2 = run(n, r, 2) if os.environ.get('BS_MODE') != 'serial' else float('nan')   # BS_MODE=serial: tools/band_share_prof.sh reads the last pass
-        print(f"N {n} rank {r}: serial {ms1:.3f} ms (efficiency {base / n / ms1:.2f})   2 in flight {ms2:.3f} ms per frame (efficiency {base / n / ms2:.2f})   frame / N = {base / n:.3f} ms")
+        more = ""
+        if os.environ.get('BS_MODE') != 'serial':   # BS_MODE=serial: tools/band_share_prof.sh reads the last pass
+            for k in (2, 3, 4):
+                ms = run(n, r, k)
+                more += f"   {k} in flight {ms:.3f} ms per frame ({base / n / ms:.2f})"
+        print(f"N {n} rank {r}: serial {ms1:.3f} ms (efficiency {base / n / ms1:.2f}){more}   frame / N = {base / n:.3f} ms")
