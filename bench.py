@@ -7,8 +7,8 @@ One "step" = one frame (one pass of the hot path over W*H*spp samples).
  * frames mode (default): with N > 1 the ranks split frame indices (progressive accumulation):
    rank r renders frame step*N + r of the replicated scene and the clamped frames are combined with one RCCL
    reduce(SUM) per step, inside the timed region.  Per-GPU work is fixed => weak scaling.
- * tiles mode: ONE frame per step, split into interleaved 64-row bands (rt_render_bands: a rank's bands are one
-   pass of the pipeline), composited with one all_gather => strong scaling.  This is the partitioning
+ * tiles mode: ONE frame per step, split into interleaved 16-row bands (multigpu.BAND_ROWS; rt_render_bands: a rank's
+   bands are one pass of the pipeline), composited with one all_gather => strong scaling.  This is the partitioning
    BASELINE.json's north_star names for configs[3] (C4).
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and `cpu_baseline`
@@ -41,6 +41,10 @@ NODE_F, TRI_F, HIT_F = 30.0, 45.0, 300.0   # flop per node test / triangle test 
 # path state crossing HBM between the launches of the wavefront pipeline, per closest-hit query (not algorithmic):
 # trace: ray 32 in, hit 24 out; shade: ray 32 + hit 24 + state 32 in, ray 32 + state 32 out (the slot rides in the state record)
 STATE_B = (32 + 24) + (32 + 24 + 32) + (32 + 32)
+
+
+def custom_size(args):
+    return bool(args.width or args.height or args.spp or args.depth)
 
 
 def build_workload(name, args):
@@ -276,8 +280,9 @@ def measure(job, workload, mode, steps, warmup, cpu_baseline):
                 "bound": "valu-issue at partial lane use + L2 latency (not HBM bandwidth; see profiles/)",
                 "achieved": hbm_gbs if by_hbm else valu_tf, "peak": HBM_PEAK_GBS if by_hbm else FP32_PEAK_TFLOPS,
                 "unit": "GB/s" if by_hbm else "TFLOP/s", "frac": max(hbm_frac, valu_frac),
-                # HBM bytes per launch come from separate rocprofv3 --pmc passes (profiles/traffic.json names the build
-                # they were taken on); they are not measurable from inside this run, so none is claimed here
+                # HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE) come from separate rocprofv3 --pmc passes of this same
+                # command (tools/pmc.sh -> profiles/traffic.json, which names the build it was taken on); they cannot be
+                # measured from inside this run, so the figure is filled in below only when that build is this one
                 "traffic": None,
                 "kernel": ("all launches of one rt_render call (wf_gen, wf_trace + wf_shade per bounce level, wf_resolve, redo)"
                            if wavefront else ("path_kernel + redo" if not args.brute else "render_kernel (brute force)")),
@@ -293,10 +298,18 @@ def measure(job, workload, mode, steps, warmup, cpu_baseline):
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath)).get(workload)
-                if tj and not args.brute and wavefront:
-                    out["roofline"]["traffic_profile"] = {"file": "profiles/traffic.json", "lib": tj.get("lib"),
-                                                          "same_build": tj.get("lib") == ctx.L.rt_version().decode(),
+                if tj and not args.brute and wavefront and not custom_size(args):
+                    same = tj.get("lib") == ctx.L.rt_version().decode()   # rt_version() carries a hash of the library's sources
+                    out["roofline"]["traffic_profile"] = {"file": "profiles/traffic.json", "lib": tj.get("lib"), "same_build": same,
                                                           "hbm_bytes_per_launch": tj.get("hbm_bytes_per_launch")}
+                    if same and tj.get("hbm_bytes_per_launch"):
+                        t = float(tj["hbm_bytes_per_launch"])
+                        out["roofline"]["traffic"] = t
+                        out["roofline"]["traffic_unit"] = "bytes per launch (one rt_render call), HBM side, from the PMC passes of this build"
+                        out["roofline"]["traffic_over_algorithmic"] = t / (alg_bytes / steps)
+                        # the share of that traffic that is the pipeline's own path state (nominal bytes per query x queries)
+                        out["roofline"]["state_share"] = out["roofline"]["state_bytes_per_ray"] * nr / steps / t
+                        out["roofline"]["traffic_hbm_frac"] = t / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
             except Exception:
                 pass
         if cpu_baseline:

@@ -64,6 +64,25 @@ _TEXTURE_MAP = weakref.WeakValueDictionary()  # path -> _TexelStore, alive while
 TEXTURE_DECODES = 0                           # files actually decoded (tests: two loads of one path decode once)
 
 
+def _decode_elsewhere(path):
+    """Files stb_image reads and rt_image_load does not (progressive and four-component JPEGs; anything else Pillow knows):
+    decoded with Pillow where it is installed, with stb_image's channel count.  A parity deviation, stated in DESIGN.md: a
+    JPEG's bytes then differ from the reference's by up to a few levels (another inverse DCT); the C++ mirror refuses such
+    files (getLoadSuccess() false: the reference's convention for an unreadable one)."""
+    import os
+    if not os.path.isfile(path):
+        return None
+    try:
+        from PIL import Image
+        im = Image.open(path)
+        im.load()
+    except Exception:
+        return None
+    if im.mode not in ("L", "LA", "RGB", "RGBA"):
+        im = im.convert("RGBA" if (im.mode == "P" and "transparency" in im.info) else "RGB")
+    return np.asarray(im, np.uint8)
+
+
 class Texture:
     """src/Material.hpp:17-50.  `Texture(path)` decodes with the library's rt_image_load (include/rt_api.h: PNG, and
     baseline JPEG with stb_image's arithmetic, so the texel bytes are what the reference's stbi_load gives -- pinned
@@ -89,6 +108,8 @@ class Texture:
             try:
                 from . import capi   # late: capi imports this module
                 arr = capi.image_load(self.path)
+                if arr is None:
+                    arr = _decode_elsewhere(self.path)
                 if arr is not None:
                     self._store.rgba8 = expand_to_rgba8(arr)
                     self._store.loadSuccess = True

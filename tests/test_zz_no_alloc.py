@@ -2,7 +2,8 @@
 device array, for callers that cannot allocate.  Checked through the C ABI against rt_render on the same
 context: same pixels, hit ids, path checksums and query counts, bit for bit -- on two calls in a row, the
 second with a smaller input (the array keeps the first call's contents), then on a frame that needs several
-chunks of the array, and its limits are refused with an error."""
+chunks of the array, and its limits are refused with an error.  And the property it exists for: the device's free
+memory is the same before and after its calls (rt_render on the same frame, right after, does take memory)."""
 import numpy as np
 import pytest
 
@@ -30,7 +31,23 @@ def test_noalloc_matches_rt_render_on_two_calls_in_a_row():
         ctx.upload_scene(scene.flatten())
         ctx.set_camera_rays(cam.preTransformRays)
         st.frameCount = 7
-        # first call: the no-alloc entry point before rt_render has ever run on this context
+        # No allocation: free device memory before and after the entry point's first calls on this context.  (One tiny call
+        # first: the HIP runtime sets up the scratch memory of kernels that spill on their first launch in a process, which is
+        # not this library's doing.)  rt_render has not run on this context, so there is no workspace from it to fall back on.
+        import torch
+        fb0 = ctx.framebuffer(cam.width, cam.height, ids=True)
+        ctx.render(cam, st, fb0, (0, 0, 8, 8), noalloc=True)
+        ctx.sync()
+        free0 = torch.cuda.mem_get_info()[0]
+        ctx.render(cam, st, fb0, noalloc=True)
+        ctx.render(cam, RenderSettings(bounceCount=9, sampleCount=7, frameCount=3), fb0, noalloc=True)
+        ctx.sync()
+        assert torch.cuda.mem_get_info()[0] == free0
+        ctx.render(cam, st, fb0)          # the allocating entry point on the same frame: its workspace shows
+        ctx.sync()
+        assert torch.cuda.mem_get_info()[0] < free0
+        ctx.framebuffer_destroy(fb0)
+        # first call compared: the no-alloc entry point against rt_render
         got1 = frame(ctx, cam, st, True)
         # second call: a smaller input (fewer samples, shallower, a ragged sub-rectangle, progressive blend)
         st2 = RenderSettings(bounceCount=3, sampleCount=2, frameCount=8, progressiveFrameCount=3)

@@ -13,8 +13,10 @@ passes=(
  "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TA_BUSY_avr"
  "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_IFETCH"
 )
+# PMC_PASSES="2 3": only those passes (FETCH_SIZE and WRITE_SIZE: the HBM traffic of tools/traffic.py)
 i=0
 for p in "${passes[@]}"; do
+  if [ -n "$PMC_PASSES" ] && ! [[ " $PMC_PASSES " == *" $i "* ]]; then i=$((i+1)); continue; fi
   timeout -s KILL 180 rocprofv3 --pmc $p --output-format csv -d $R/$out/pass$i -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --also '' "$@" > $R/$out/pass$i.log 2>&1 || { echo "pass $i failed"; tail -3 $R/$out/pass$i.log; exit 1; }
   i=$((i+1))
 done

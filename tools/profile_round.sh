@@ -23,4 +23,11 @@ for w in c2 c4; do
   python3 tools/pmc_levels.py gpurun_out/pmc_${tag}_$w > gpurun_out/${tag}_${w}_pmc_levels.txt
   python3 tools/traffic.py gpurun_out/pmc_${tag}_$w $w 3 > gpurun_out/${tag}_${w}_traffic.json
 done
+for w in c3 c5; do   # HBM traffic only
+  rm -rf gpurun_out/pmc_${tag}_$w
+  PMC_PASSES="2 3" bash tools/pmc.sh gpurun_out/pmc_${tag}_$w --workload $w > gpurun_out/${tag}_${w}_pmc.txt 2>&1 || exit 1
+  python3 tools/traffic.py gpurun_out/pmc_${tag}_$w $w 3 > gpurun_out/${tag}_${w}_traffic.json
+done
+python3 tools/traffic.py merge gpurun_out/${tag}_c2_traffic.json gpurun_out/${tag}_c4_traffic.json gpurun_out/${tag}_c3_traffic.json gpurun_out/${tag}_c5_traffic.json > gpurun_out/${tag}_traffic.json
+# the bench line again, now that profiles/traffic.json can be of this build: copy gpurun_out/${tag}_traffic.json there first
 echo done
