@@ -149,7 +149,7 @@ struct WfBufs {
     float4* hitA;        // [kWfStripes][subCap] t, b0, b1, b2 of the closest hit (trace -> shade of one level)
     uint2* hitM;         // [kWfStripes][subCap] gid | flags, object: with the object named here the shade kernel starts the triangle
                          // and the object-cull fetches of a hit at once instead of one after the other
-    float4* out;         // [slot] finished sample: exposure-corrected rgb, checksum bits
+    float4* out;         // [slot] the sample's outgoing light so far (final once its path has ended; wf_resolve applies the exposure), checksum bits
     uint8_t* outRays;    // [slot] closest-hit queries of the finished sample
     uint32_t* redoSlots; // [kWfStripes][subCap] the samples (slots) whose path the redo launch traces again with the exact in-order
                          // emulation inline, listed under the stripe they live in (a sample is listed at most once: its path ends there)

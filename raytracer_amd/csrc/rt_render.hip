@@ -869,8 +869,7 @@ __global__ __launch_bounds__(256) void wf_gen_kernel(const RenderArgs a, const W
                     uint32_t* idp = reinterpret_cast<uint32_t*>(a.ids + ((size_t)y * (size_t)a.width + (size_t)x));
                     idp[0] = kNoHit; idp[1] = kNoHit; idp[2] = kNoHit;
                 }
-                const float e = 1.0f - rtd::exp_f(-0.0f * a.exposure);
-                w.out[wf_out_index(pix, sidx, spp)] = make_float4(e, e, e, __uint_as_float(0u));
+                w.out[wf_out_index(pix, sidx, spp)] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
                 w.outRays[wf_out_index(pix, sidx, spp)] = 0;
             }
         }
@@ -1384,11 +1383,22 @@ __device__ __forceinline__ void shade_entry(const RenderArgs& a, const WfBufs& w
     }
     if (o.more) { // kept in registers until the survivors' positions are known
         o.ray = ray; o.seed = seed; o.chk = checksum; o.acc = acc;
+        // ... and what the sample is worth if the bounce ray misses everything (the next iteration's :176-183, its inputs all
+        // here) is stored now, as the sample's result so far: three quarters of a bounce level's rays do miss, and a miss then
+        // has nothing left to do -- the level's shade launch never reads its path state (48 bytes a ray) and never runs a
+        // wave for it.  A ray that hits overwrites the result when its own path ends (or with its own next what-if).
+        const V4 miss = sky_light(mk4(ray.dx, ray.dy, ray.dz, 0.0f), a);
+        float sx = acc.ox, sy = acc.oy, sz = acc.oz;
+        sx += miss.x * miss.w * acc.bx;
+        sy += miss.y * miss.w * acc.by;
+        sz += miss.z * miss.w * acc.bz;
+        const size_t oi = wf_out_index(pix, sidx, spp);
+        w.out[oi] = make_float4(sx, sy, sz, __uint_as_float(checksum + seg_hash(kNoHit, kNoHit, kNoHit, sidx, (uint32_t)(level + 1))));
+        w.outRays[oi] = (uint8_t)(level + 2 > 255 ? 255 : level + 2);
     } else
     { // exposureCorrection (:690-698), per sample
         const size_t oi = wf_out_index(pix, sidx, spp);
-        w.out[oi] = make_float4(1.0f - rtd::exp_f(-acc.ox * a.exposure), 1.0f - rtd::exp_f(-acc.oy * a.exposure),
-                                1.0f - rtd::exp_f(-acc.oz * a.exposure), __uint_as_float(checksum));
+        w.out[oi] = make_float4(acc.ox, acc.oy, acc.oz, __uint_as_float(checksum));
         w.outRays[oi] = (uint8_t)(level + 1 > 255 ? 255 : level + 1);
     }
 }
@@ -1460,8 +1470,10 @@ __global__ __launch_bounds__(256, DEAL ? RT_SHADE_OCC : RT_SHADE_OCC + 1) void w
                 const uint32_t off = base + j * 256u + threadIdx.x;
                 const bool in = j < nbp && off < cnt;
                 const uint32_t g0 = in ? w.hitM[wf_hit_pos(w, stripe, off)].x : kWfMiss;
-                const bool isHit = in && (g0 & kWfMiss) != kWfMiss;   // no holes past the camera rays
-                const bool isMiss = in && !isHit;
+                // a miss has nothing left to do: its result was stored when the ray was made (shade_entry).  One that carries the
+                // flag of a dropped stack entry goes the way of the hits, which sends its sample to the redo launch
+                const bool isHit = in && ((g0 & kWfMiss) != kWfMiss || (g0 & kWfDanger) != 0u);   // no holes past the camera rays
+                const bool isMiss = false;
                 cls |= (isHit ? 1u : (isMiss ? 2u : 0u)) << (2u * j);
                 const unsigned long long hb = __ballot(isHit), mb = __ballot(isMiss);
                 if (lane == 0) { runCnt[0][j * 4u + wave] = (uint32_t)__popcll(hb); runCnt[1][j * 4u + wave] = (uint32_t)__popcll(mb); }
@@ -1515,8 +1527,10 @@ __device__ __forceinline__ void wf_resolve_pixel(const RenderArgs& a, const WfBu
         float pr = 0.0f, pg = 0.0f, pb = 0.0f; // a z lane without samples contributes 0
         for (uint32_t sidx = z; sidx < spp; sidx += 4u) {
             const size_t oi = wf_out_index(pix, sidx, spp);
-            const float4 v = w.out[oi];
-            pr += v.x; pg += v.y; pb += v.z;
+            const float4 v = w.out[oi]; // the sample's outgoing light; the exposure (:185-187) is applied here, once per sample
+            pr += 1.0f - rtd::exp_f(-v.x * a.exposure);
+            pg += 1.0f - rtd::exp_f(-v.y * a.exposure);
+            pb += 1.0f - rtd::exp_f(-v.z * a.exposure);
             checksum += __float_as_uint(v.w);
             rays += w.outRays[oi];
         }
@@ -1585,8 +1599,7 @@ __global__ __launch_bounds__(256) void wf_redo_kernel(const RenderArgs a, const 
         const uint32_t rays0 = st.rays;
         const V4 c = trace_path<2>(a, ray, seed, sidx, stack, st, checksum, primary);
         const size_t oi = wf_out_index(pix, sidx, spp);
-        w.out[oi] = make_float4(1.0f - rtd::exp_f(-c.x * a.exposure), 1.0f - rtd::exp_f(-c.y * a.exposure),
-                                1.0f - rtd::exp_f(-c.z * a.exposure), __uint_as_float(checksum));
+        w.out[oi] = make_float4(c.x, c.y, c.z, __uint_as_float(checksum));
         w.outRays[oi] = (uint8_t)(st.rays - rays0);
         if (sidx == 0 && a.ids) {
             uint32_t* idp = reinterpret_cast<uint32_t*>(a.ids + ((size_t)y * (size_t)a.width + (size_t)x));
