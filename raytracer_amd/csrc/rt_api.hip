@@ -43,7 +43,9 @@ struct MeshRec {
     float* pos = nullptr; int32_t* idx = nullptr; float* uv = nullptr; float* nrm = nullptr;
     int32_t nVerts = 0, nTris = 0;
 };
-struct TexRec { bool live = false; uchar4* data = nullptr; int32_t w = 0, h = 0; };
+// red: the first channel alone, one byte per texel, behind the RGBA texels in the same allocation (what a roughness or
+// metal binding samples, rt_render.hip tex2d_norm_red)
+struct TexRec { bool live = false; uchar4* data = nullptr; uint8_t* red = nullptr; int32_t w = 0, h = 0; };
 struct MatRec { bool live = false; rt_material_desc desc; };
 struct ObjRec {
     bool live = false;
@@ -141,7 +143,8 @@ rt::DevMaterial to_dev(const rt_material_desc& d, const std::vector<TexRec>& tex
     const rt_id t[4] = { d.texNormal, d.texAlbedo, d.texRoughness, d.texMetal };
     for (int i = 0; i < 4; i++)
         if (t[i] >= 0 && (size_t)t[i] < textures.size() && textures[t[i]].live) {
-            m.tex[i].data = textures[t[i]].data; m.tex[i].w = textures[t[i]].w; m.tex[i].h = textures[t[i]].h;
+            m.tex[i].data = i >= 2 ? reinterpret_cast<const uchar4*>(textures[t[i]].red) : textures[t[i]].data;
+            m.tex[i].w = textures[t[i]].w; m.tex[i].h = textures[t[i]].h;
         }
     memcpy(m.albedo, d.albedo, sizeof(m.albedo));
     m.roughness = d.roughness; m.metal = d.metal;
@@ -565,8 +568,13 @@ int rt_texture_create(rt_ctx* c, const uint8_t* rgba8, int32_t w, int32_t h, rt_
     RT_BIND(c);
     if (!out || !rgba8 || w <= 0 || h <= 0) return fail(c, RT_ERR_INVALID, "texture needs rgba8 data and positive extents");
     TexRec t; t.w = w; t.h = h;
-    RT_CHECK(c, hipMalloc((void**)&t.data, (size_t)w * (size_t)h * 4));
-    hipError_t e = hipMemcpy(t.data, rgba8, (size_t)w * (size_t)h * 4, hipMemcpyHostToDevice);
+    const size_t n = (size_t)w * (size_t)h;
+    RT_CHECK(c, hipMalloc((void**)&t.data, n * 5));
+    t.red = reinterpret_cast<uint8_t*>(t.data) + n * 4;
+    std::vector<uint8_t> red(n);
+    for (size_t i = 0; i < n; i++) red[i] = rgba8[i * 4];
+    hipError_t e = hipMemcpy(t.data, rgba8, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t.red, red.data(), n, hipMemcpyHostToDevice);
     if (e != hipSuccess) { hipFree(t.data); return fail(c, RT_ERR_HIP, std::string("texture upload failed: ") + hipGetErrorString(e)); }
     t.live = true;
     const rt_id id = alloc_slot(c->textures);

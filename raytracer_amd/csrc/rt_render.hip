@@ -113,6 +113,20 @@ __device__ __forceinline__ V4 tex2d_norm(const DevTexture& t, float u, float v)
     return bilerp(texel8(t, tx.i0, ty.i0), texel8(t, tx.i1, ty.i0), texel8(t, tx.i0, ty.i1), texel8(t, tx.i1, ty.i1),
                   tx.a, ty.a);
 }
+// The roughness and metal maps are read in their first channel only (Material.cu:268-323): the material record points at a
+// one-byte-per-texel copy of that channel (rt_api.hip, to_dev), a quarter of the footprint for the same texels -- on the
+// incoherent hits of the bounce levels the texel fetches are what wf_shade waits for (C4: 70 % of its L2 requests miss).
+__device__ __forceinline__ float tex2d_norm_red(const DevTexture& t, float u, float v)
+{
+    const uint8_t* __restrict__ d = reinterpret_cast<const uint8_t*>(t.data);
+    const Tap tx = make_tap(u * (float)t.w - 0.5f, t.w);
+    const Tap ty = make_tap(v * (float)t.h - 0.5f, t.h);
+    const float t00 = rtd::byte_unorm(d[(size_t)ty.i0 * (size_t)t.w + (size_t)tx.i0]), t10 = rtd::byte_unorm(d[(size_t)ty.i0 * (size_t)t.w + (size_t)tx.i1]);
+    const float t01 = rtd::byte_unorm(d[(size_t)ty.i1 * (size_t)t.w + (size_t)tx.i0]), t11 = rtd::byte_unorm(d[(size_t)ty.i1 * (size_t)t.w + (size_t)tx.i1]);
+    const float a = tx.a, b = ty.a;
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    return ((w00 * t00 + w10 * t10) + w01 * t01) + w11 * t11;   // bilerp().x
+}
 __device__ __forceinline__ V4 ray_texel(const float4* __restrict__ tab, int w, int x, int y)
 {
     const float4 p = tab[(size_t)y * (size_t)w + (size_t)x];
@@ -227,8 +241,8 @@ __device__ __forceinline__ Surface shade_surface(const SceneView& s, const Hit& 
                       tangent.z * nl.x + bitangent.z * nl.y + normal.z * nl.z + 0.0f * nl.w,
                       0.0f * nl.x + 0.0f * nl.y + 0.0f * nl.z + 1.0f * nl.w);
     o.normal = normalize4(nw);
-    o.roughness = m.texRoughness < 0 ? m.roughness : tex2d_norm(mp->tex[2], u, v).x;
-    o.metal = m.texMetal < 0 ? m.metal : tex2d_norm(mp->tex[3], u, v).x;
+    o.roughness = m.texRoughness < 0 ? m.roughness : tex2d_norm_red(mp->tex[2], u, v);
+    o.metal = m.texMetal < 0 ? m.metal : tex2d_norm_red(mp->tex[3], u, v);
     o.emission = mk4(m.emission[0], m.emission[1], m.emission[2], m.strength);
     return o;
 }
