@@ -213,7 +213,8 @@ int rt_render_noalloc(rt_ctx* ctx, const rt_camera_params* camera, const rt_rend
  * Exact in every traversal mode, including the reference's order-dependent cases: ties between objects, hits that lie
  * before their object's bounding-box entry, and the noise hits its triangle test reports on triangles of no area
  * (collinear vertices), which no bounding box can stand for.  rt_render gives the same pixels as
- * the reference in all of these but the last, where the hot kernels rely on a camera or bounce ray not passing within
+ * the reference in all of these; in the last, camera rays are tested against the listed lines where they are made and
+ * take the exact walks when they come near, while bounce rays (directions out of the RNG) rely on not passing within
  * ~1e-7 of such a triangle's line (measured: never in 2e8 rays on the reference's sword); RT_OPT_TRAVERSAL = 1 removes
  * that reliance at brute-force cost. */
 int rt_trace_rays(rt_ctx* ctx, const float* rays, int32_t nRays, uint32_t* out);

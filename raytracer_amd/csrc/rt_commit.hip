@@ -185,18 +185,22 @@ __global__ __launch_bounds__(256) void morton_kernel(const TriIsect* __restrict_
 
 // Triangles of (nearly) no area.  The reference's watertight test decides by the signs of three edge functions computed in
 // binary32; when the ray passes within rounding of the LINE through a collinear triangle, all three are rounding noise and a
-// hit is reported a quarter of the time -- wherever along that line the triangle lies, at a "hit point" inside the triangle
-// and so possibly far from the ray.  No bounding box can stand for that: a BVH walk never gets near such a triangle
-// (tests/soak_parity.py: objects with two axes scaled to zero, rays aimed at their vertices: 6 of 18 M ray queries returned a
-// farther hit; the reference's own sword model holds ten such triangles).  An edge function is p_a x p_b with an error of
+// hit is reported a third of the time when the point where the ray crosses the line lies inside the triangle's span (never
+// when it does not: 0 of 54 000 such rays, measured with the oracle).  The distance reported is a mean of the three vertex
+// depths under weights of rounding noise: anywhere along the sliver, up to 1e-2 outside the stretch of the ray that the
+// sliver's bounding box holds, so a walk that has found something nearer or an overlapping sliver first prunes the box and
+// never tests the triangle (tests/soak_parity.py: objects with two axes scaled to zero, rays aimed at their vertices: 6 of
+// 18 M ray queries returned a farther hit; the reference's own sword model holds ten such triangles).  An edge function is p_a x p_b with an error of
 // 2^-22 |p_a||p_b|, so a violated edge decides correctly unless it subtends less than 2^-22 rad at the crossing point; for a
 // triangle of altitude w seen from up to 2 S away (S = the scene's largest |coordinate|) that needs w < 2^-20 S.  Triangles
 // with altitude below 2^-17 S are listed here, as the line they lie on, and the walks of the exact paths (bvh_walk: every
 // rt_trace_rays query, the redo launches, wf_exact) test them after the tree, behind a cheap test of the ray's distance to that
-// line (rt_trace.h, thin_near).  The hot render kernels do NOT: for a camera or bounce ray to pass within ~1e-7 of such a line
-// does not happen -- 200 M rays of a C3 frame (tools/thin_check.py) are identical to the brute-force mode without any of
-// this -- and looking out for it in wf_shade cost C3 a fifth of its frame time.  RT_OPT_TRAVERSAL = 1 is there for a caller
-// who needs the guarantee on such a scene.  The triangles stay in the tree as well (testing one twice changes nothing).  A
+// line (rt_trace.h, thin_near).  Camera rays -- the rays a scene can aim at such a line by construction -- are tested against
+// every listed line where they are made (wf_gen, path_kernel) and sent to the exact walks when they come near
+// (tests/thin_scene.py aims them on purpose; the test fails without it).  Bounce rays are not: their directions come out of
+// the RNG, and one passing within ~1e-7 of a given line was not seen in 200 M rays of a C3 frame (tools/thin_check.py), while
+// looking out for it in wf_shade cost C3 a fifth of its frame time.  RT_OPT_TRAVERSAL = 1 is there for a caller who needs
+// the guarantee for those too.  The triangles stay in the tree as well (testing one twice changes nothing).  A
 // triangle of no extent at all, or with a vertex that is not finite, is never hit (all three edge functions are exactly 0,
 // or NaN) and is not listed.
 __global__ __launch_bounds__(256) void thin_kernel(const TriIsect* __restrict__ triRef, uint32_t nTris, float tau,

@@ -889,7 +889,7 @@ __global__ __launch_bounds__(256) void wf_gen_kernel(const RenderArgs a, const W
         }
     }
     // The triangles no box can stand for (rt_commit.hip, thin_kernel; rt_trace.h, thin_near): a ray that passes within rounding
-    // of the LINE such a triangle lies on can "hit" it wherever along that line it sits, so no walk of the tree finds it.  Camera
+    // of the LINE such a triangle lies on can "hit" it at a distance outside what the sliver's box holds, so a walk of the tree can miss it.  Camera
     // rays are the rays that can be aimed at such a line by construction (an axis-aligned camera without anti-aliasing over
     // gridded geometry puts pixel centres on vertices), so every camera ray is tested against every listed line here, and one
     // that comes near goes to the redo launch, whose walks test the listed triangles (bvh_walk).  With the origin common to all
