@@ -38,9 +38,18 @@ FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector
 NODE_B, TRI_B = 64.0, 48.0                 # one four-wide BVH node; 3 x i32 + 3 x 3 x f32 per triangle test (8d)
 HIT_B, MAP_B = 12.0 + 96.0, 16.0           # per shaded hit: 3 indices + 3 x (12 + 12 + 8) B attributes; 4 texels x 4 B per bound map
 NODE_F, TRI_F, HIT_F = 30.0, 45.0, 300.0   # flop per node test / triangle test / shaded hit (8d)
-# path state crossing HBM between the launches of the wavefront pipeline, per closest-hit query (not algorithmic):
-# trace: ray 32 in, hit 24 out; shade: ray 32 + hit 24 + state 32 in, ray 32 + state 32 out (the slot rides in the state record)
-STATE_B = (32 + 24) + (32 + 24 + 32) + (32 + 32)
+# Path state crossing HBM between the launches of the wavefront pipeline (not algorithmic), in bytes:
+#   a camera ray: direction 16 written by wf_gen, read by the packet kernel and by wf_shade; hit word 8 written and read
+#   a bounce ray: 64 written by wf_shade (origin, direction, light, beta + slot), 32 of them read by wf_trace; hit word 8 written,
+#                 and read by the dealing pass
+#   a hit: t / barycentrics 16 written and read; at a bounce level also the 64 of its state and its hit word again (gathered)
+#   a sample: result 17 written when the path ends and read by wf_resolve; written once more for every bounce ray made
+#             (its what-if-it-misses result: misses of the bounce levels are never touched again)
+def state_bytes(n_camera, n_rays, n_hits):
+    n_bounce = n_rays - n_camera
+    bounce_hits = n_hits * n_bounce / max(n_rays, 1.0)   # the counters do not split the hits by level: pro rata
+    return (n_camera * (16 * 3 + 8 * 2) + n_bounce * (64 + 32 + 8 * 2) + n_hits * (16 * 2) + bounce_hits * (64 + 8)
+            + 17.0 * (2 * n_camera + n_bounce))
 
 
 def custom_size(args):
@@ -289,8 +298,8 @@ def measure(job, workload, mode, steps, warmup, cpu_baseline):
                 "kernel_ms": kernel_ms,
                 "hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_frac, "bytes_per_ray": alg_bytes / nr},
                 "valu": {"achieved": valu_tf, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": valu_frac, "flop_per_ray": alg_flops / nr},
-                # the pipeline's own HBM traffic per query: ray / hit / accumulator records between launches + 34 B per sample of result
-                "state_bytes_per_ray": (float(STATE_B) + 34.0 * st.sampleCount * pix_local / nr) if wavefront else 0.0,
+                # the pipeline's own HBM traffic per query (state_bytes above): nominal, from the counts of this run
+                "state_bytes_per_ray": (state_bytes(float(st.sampleCount) * pix_local, float(nr), float(s.hits)) / nr) if wavefront else 0.0,
                 "nodes_per_ray": s.node_visits / nr, "node_fetches_per_ray": node_fetches / nr,
                 "tris_per_ray": s.tri_tests / nr, "hits_per_ray": s.hits / nr, "slow_path_frac": s.slow_path / nr},
         }

@@ -104,8 +104,8 @@ enum rt_option {
                              frames), 1 = Karras radix tree (scenes re-committed every frame).  Same pixels. */
     RT_OPT_REFIT = 8,     /* 1 (default): rt_scene_commit of the same objects and meshes under other matrices keeps the tree of
                              the last full build and refits its boxes (a moved 1 M-triangle scene in 1.6 ms instead of 5.5),
-                             unless the refitted boxes sum to more than 1.5 times the built tree's area (then the next frame
-                             would lose more than the commit saved, and the tree is built anew); 0: every commit builds;
+                             unless the refitted boxes sum to more than 1.3 times the built tree's area (the next frames
+                             would then lose to the looser boxes what the commit saved, and the tree is built anew); 0: every commit builds;
                              101 ...: that limit in percent.  Same pixels either way. */
     RT_OPT_WF_LANE = 7    /* frames in flight: the workspace lane (0 .. 3, default 0) the following rt_render / rt_render_bands
                              calls use first.  Two calls that use different lanes AND run on different streams (rt_set_stream)

@@ -23,7 +23,10 @@ constexpr size_t kCntBytes = sizeof(unsigned long long) * rt::kCounterSlots * rt
 // A refitted tree whose node boxes sum to more than this times the built tree's area is rebuilt.  Measured on C4 (331 bins
 // jittered independently, tools/refit_probe.py): area x 1.29 -> frame +15 %, x 1.54 -> +18 %, x 1.74 -> +34 %, x 1.93 -> +53 %,
 // against 3.9 ms that a refit (1.6 ms) saves over a build (5.5 ms): past x 1.5 the next frame loses more than the commit won.
-constexpr int kRefitGrowthDefault = 150;   // percent   // a refitted tree whose node boxes sum to more than this times the built tree's area is rebuilt
+// A refitted tree whose node boxes sum to more than this (percent) times the built tree's area is rebuilt.  Measured on C4
+// (tools/refit_probe.py): the frame on a refitted tree costs +0.3 ms at 1.10 x the area, +1.1 at 1.17, +1.4 at 1.25, +4.0 at
+// 1.5, against the 3.6 ms a refit saves over a build -- and on the next commit the rebuilt tree refits from 1.0 again.
+constexpr int kRefitGrowthDefault = 130;
 
 thread_local std::string g_createError;
 

@@ -1,11 +1,15 @@
+"""Frame time of a refitted tree against the growth of its node area: a scene's objects nudged step by step, re-committed
+(RT_OPT_REFIT limit from REFIT=percent; RT_AMD_DEBUG_BUILD=1 prints the area ratio of every refit), a frame timed after each.
+   REFIT=400 RT_AMD_DEBUG_BUILD=1 python tools/refit_probe.py config4 0.1     # and REFIT=0 for the rebuilt tree at the same poses"""
 import sys, os, time
 import numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch; torch.cuda.is_available()
 from raytracer_amd import capi, scenes
 name = sys.argv[1]
 scene, cam, st = getattr(scenes, name)()
 ctx = capi.Context(0)
+if os.environ.get("REFIT"): ctx.set_option(capi.OPT_REFIT, int(os.environ["REFIT"]))   # growth limit in percent, 0 = always rebuild
 flat = scene.flatten(); ids = ctx.upload_scene(flat); ctx.set_camera_rays(cam.preTransformRays)
 fb = ctx.framebuffer(cam.width, cam.height)
 def frame_ms():
