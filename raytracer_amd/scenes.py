@@ -44,7 +44,7 @@ def procedural_texture(size=1024, seed=7, kind="albedo"):
     b = g[i + 1][:, i] * (1 - f)[None, :, None] + g[i + 1][:, i + 1] * f[None, :, None]
     v = a * (1 - f)[:, None, None] + b * f[:, None, None]
     if kind == "albedo":
-        stripes = ((np.arange(size) // (size // 32)) % 2).astype(np.float32)
+        stripes = ((np.arange(size) // max(1, size // 32)) % 2).astype(np.float32)
         rgb = 0.25 + 0.7 * v
         rgb[..., 0] *= 0.8 + 0.2 * stripes[None, :]
     elif kind == "normal":
