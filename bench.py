@@ -161,7 +161,7 @@ def measure(job, workload, mode, steps, warmup, cpu_baseline):
         frame_t = bufs[0]
     else:
         # two frames in flight: the all_gather of frame i runs on a side stream while frame i + 1 renders
-        tc = multigpu.TileCompositor(torch, dist, W, H, rank, world, dev, buffers=2 if world > 1 else 1)
+        tc = multigpu.TileCompositor(torch, dist, W, H, rank, world, dev, buffers=2 if (world > 1 or job.lanes) else 1)   # a buffer per frame in flight
         fbs = [ctx.framebuffer_wrap(f.data_ptr(), W, H) for f in tc.frames]
         frame_t = tc.frames[0]
 
@@ -202,7 +202,7 @@ def measure(job, workload, mode, steps, warmup, cpu_baseline):
                 ctx.render(cam, st, fbs[b], bands=(multigpu.BAND_ROWS, rank, world))
                 tc.submit(b)
             else:
-                ctx.render(cam, st, fbs[0])
+                ctx.render(cam, st, fbs[frame_base % len(fbs)])
 
     def barrier():
         if fa is not None:
