@@ -307,7 +307,7 @@ def measure(job, workload, mode, steps, warmup, cpu_baseline):
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath)).get(workload)
-                if tj and not args.brute and wavefront and not custom_size(args):
+                if tj and not args.brute and wavefront and not custom_size(args) and (world == 1 or mode == "frames"):   # the profile is of whole frames
                     same = tj.get("lib") == ctx.L.rt_version().decode()   # rt_version() carries a hash of the library's sources
                     out["roofline"]["traffic_profile"] = {"file": "profiles/traffic.json", "lib": tj.get("lib"), "same_build": same,
                                                           "hbm_bytes_per_launch": tj.get("hbm_bytes_per_launch")}
