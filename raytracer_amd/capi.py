@@ -218,9 +218,10 @@ class Context:
 
     def commit(self, object_ids, models, invs):
         n = len(object_ids)
-        oid = np.array(object_ids, np.int32)
-        mm = np.ascontiguousarray(np.stack(models) if n else np.zeros((0, 16)), np.float32)
-        im = np.ascontiguousarray(np.stack(invs) if n else np.zeros((0, 16)), np.float32)
+        oid = np.ascontiguousarray(object_ids, np.int32)
+        # (n, 16) arrays are taken as they are: stacking 10 000 small arrays costs more than the library's commit of them
+        mm = np.ascontiguousarray(models if isinstance(models, np.ndarray) else (np.stack(models) if n else np.zeros((0, 16))), np.float32).reshape(n, 16)
+        im = np.ascontiguousarray(invs if isinstance(invs, np.ndarray) else (np.stack(invs) if n else np.zeros((0, 16))), np.float32).reshape(n, 16)
         self.check(self.L.rt_scene_commit(self.h, _ptr(oid) if n else None, _ptr(mm) if n else None,
                                           _ptr(im) if n else None, n))
 

@@ -29,9 +29,10 @@ for name in (sys.argv[1:] or ("config2", "config4", "config5")):
             for o in objs[1:] if len(objs) > 1 else objs:
                 o.setPosition(tuple(np.asarray(o.Position, np.float32) + rng.uniform(-0.3, 0.3, 3).astype(np.float32)))
             fl = scene.flatten()
-            models = [np.asarray(o["model"], np.float32) for o in fl.objects]
-            invs = [np.asarray(o["invModel"], np.float32) for o in fl.objects]
-            t0 = time.perf_counter(); ctx.commit(ids["obj"], models, invs); ctx.sync(); ts.append(time.perf_counter() - t0)
+            models = np.stack([np.asarray(o["model"], np.float32).reshape(16) for o in fl.objects])
+            invs = np.stack([np.asarray(o["invModel"], np.float32).reshape(16) for o in fl.objects])
+            oid = np.asarray(ids["obj"], np.int32)
+            t0 = time.perf_counter(); ctx.commit(oid, models, invs); ctx.sync(); ts.append(time.perf_counter() - t0)   # the C ABI call and its GPU work
             kinds.append(ctx.commit_kind())
         f1 = frame_ms()
         print(name, "builder", ("PLOC", "radix")[builder], "refit" if refit else "rebuild", "tris %d  first upload+commit %.1f ms  re-commit %s ms (GPU part %.2f ms) kinds %s  frame before %.2f ms, after the moves %.2f ms" % (
