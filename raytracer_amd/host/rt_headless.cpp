@@ -128,6 +128,21 @@ int main(int argc, char** argv)
                 if (fwrite(px.data(), 4, px.size(), f) != px.size()) return 6;
             }
             fclose(f);
+            // the instance table is committed when something changed, not per frame: seven frames of a static scene are one
+            // rt_scene_commit; a moved object is one more, and a refit of the tree (rt_scene_commit_kind 2); a mesh created
+            // on the context in between (another object's) makes the next commit a full one again
+            if (dev.sceneCommits != 1) return 14;
+            scene.getObjects()[1].second->setPosition(vec3{ 1.4f, 0.1f, 0.0f });
+            rt.raytrace(scene, cam, fb);
+            if (dev.sceneCommits != 2 || rt_scene_commit_kind(dev.ctx()) != 2) return 15;
+            rt.raytrace(scene, cam, fb);
+            if (dev.sceneCommits != 2) return 16;
+            {
+                auto extra = std::make_shared<Cube>(dev);
+                extra->setMaterial(def); extra->sendToGPU();
+                rt.raytrace(scene, cam, fb);
+                if (dev.sceneCommits != 3 || rt_scene_commit_kind(dev.ctx()) != 1) return 17;
+            }
             // sharing: two Textures of one path upload once; two CustomModels of one path parse and upload once
             fb.savePNG(argv[5]);
             {

@@ -103,6 +103,11 @@ public:
     // customModels, CustomModel.cpp:10-24): an entry lives while any Texture / CustomModel of that path does
     std::unordered_map<std::string, std::weak_ptr<void>> textureMap, modelMap;
     int textureUploads = 0, modelParses = 0;   // what actually reached the device / the parser (tests)
+    // what Scene::commit needs to tell "nothing changed" from "the same handle numbers, other contents": every mesh and
+    // object this mirror creates or destroys on the context counts, and so does whichever scene committed last
+    unsigned long long uploadEpoch = 0;
+    const void* lastCommitter = nullptr;
+    int sceneCommits = 0;                      // rt_scene_commit calls made (tests)
 private:
     rt_ctx* ctx_ = nullptr;
 };
@@ -239,10 +244,11 @@ public:
         triangleCount = (int)indices.size() / 3;
         for (size_t i = 0; i + 2 < vertices.size(); i += 3) // calcBounds, Mesh.hpp:106-122
             for (int k = 0; k < 3; k++) { minBound[k] = std::min(minBound[k], vertices[i + k]); maxBound[k] = std::max(maxBound[k], vertices[i + k]); }
+        dev_.uploadEpoch++;
         dev_.check(rt_mesh_create(dev_.ctx(), vertices.data(), (int)vertices.size() / 3, indices.data(), triangleCount,
                                   uvCoords.empty() ? nullptr : uvCoords.data(), normals.empty() ? nullptr : normals.data(), &id_));
     }
-    ~Mesh() { if (id_ >= 0) rt_mesh_destroy(dev_.ctx(), id_); }
+    ~Mesh() { if (id_ >= 0) { rt_mesh_destroy(dev_.ctx(), id_); dev_.uploadEpoch++; } }
     Mesh(const Mesh&) = delete;
     const float* getMinBound() const { return minBound; }
     const float* getMaxBound() const { return maxBound; }
@@ -264,7 +270,7 @@ private:
 class DisplayObject {
 public:
     DisplayObject(Device& dev, vec3 position = {}, quat rotation = {}, vec3 scl = { 1, 1, 1 }) : dev_(dev), Position(position), Rotation(rotation), Scale(scl) {}
-    virtual ~DisplayObject() { if (id_ >= 0) rt_object_destroy(dev_.ctx(), id_); }
+    virtual ~DisplayObject() { if (id_ >= 0) { rt_object_destroy(dev_.ctx(), id_); dev_.uploadEpoch++; } }
     mat4 getModelMatrix() const { mat4 m = identity(); m = translate(m, Position); m = mul(m, mat4_cast(Rotation)); return scale(m, Scale); }
     mat4 getInverseModelMatrix() const { return inverse(getModelMatrix()); }
     void setPosition(vec3 p) { Position = p; }
@@ -285,6 +291,7 @@ public:
         for (auto& p : meshes) { mi.push_back(p.first->id()); mx.push_back(p.second); }
         for (auto& m : materials) ma.push_back(m->id());
         if (id_ >= 0) { rt_object_destroy(dev_.ctx(), id_); id_ = -1; }
+        dev_.uploadEpoch++;
         dev_.check(rt_object_create(dev_.ctx(), mi.data(), mx.data(), (int)mi.size(), ma.data(), (int)ma.size(), compositeMinBounds, compositeMaxBounds, &id_));
     }
     rt_id id() { if (id_ < 0) sendToGPU(); return id_; }
@@ -434,8 +441,11 @@ public:
     }
     std::vector<std::pair<std::string, std::shared_ptr<DisplayObject>>>& getObjects() { return objects_; }
     void sendToGPU() { for (auto& p : objects_) p.second->sendToGPU(); }
-    // getGPUObjectDataVector: instance table = (model, inverse(model)) per object -> rt_scene_commit
-    void commit()
+    // getGPUObjectDataVector: instance table = (model, inverse(model)) per object -> rt_scene_commit.  The reference builds
+    // that table every frame; here the call is made when something changed (scene->dirty()) -- the object
+    // list, a transform, or any mesh / object created or destroyed on the context since this scene's last commit -- and the
+    // library then refits or rebuilds (rt_scene_commit_kind).  force = true commits regardless.
+    void commit(bool force = false)
     {
         std::vector<rt_id> ids; std::vector<float> model, inv;
         for (auto& p : objects_) {
@@ -443,10 +453,17 @@ public:
             const mat4 m = p.second->getModelMatrix(), im = inverse(m);
             model.insert(model.end(), &m.c[0][0], &m.c[0][0] + 16); inv.insert(inv.end(), &im.c[0][0], &im.c[0][0] + 16);
         }
+        const bool same = !force && dev_.lastCommitter == this && lastEpoch_ == dev_.uploadEpoch && ids == lastIds_ &&
+                          model.size() == lastModel_.size() &&
+                          (model.empty() || memcmp(model.data(), lastModel_.data(), model.size() * sizeof(float)) == 0);
+        if (same) return;
         dev_.check(rt_scene_commit(dev_.ctx(), ids.data(), model.data(), inv.data(), (int)ids.size()));
+        dev_.sceneCommits++;
+        dev_.lastCommitter = this; lastEpoch_ = dev_.uploadEpoch; lastIds_ = std::move(ids); lastModel_ = std::move(model);
     }
 private:
     Device& dev_;
+    std::vector<rt_id> lastIds_; std::vector<float> lastModel_; unsigned long long lastEpoch_ = ~0ull;
     std::vector<std::pair<std::string, std::shared_ptr<DisplayObject>>> objects_;
 };
 
