@@ -178,8 +178,10 @@ struct Surface {
 // winner attributes (:435-548) + material evaluation (:363-377, Material.cu:268-323)
 // matHint: the winner's TriShade::matFlags when the caller already has it (the wavefront hit record), so that the
 // material fetch does not wait for the triangle record; kNoHit = take it from the record
+// full = false: the path ends at this hit (the last iteration of the bounce loop, :172) and the hit is not a camera ray's, so
+// only the ids and the emission are used: no tangent frame, no texel (needAlbedo: the ambient term of a camera ray would)
 __device__ __forceinline__ Surface shade_surface(const SceneView& s, const Hit& h, uint32_t& objOut, uint32_t& meshOut,
-                                                 uint32_t& triOut, uint32_t matHint = kNoHit)
+                                                 uint32_t& triOut, uint32_t matHint = kNoHit, bool full = true, bool needAlbedo = true)
 {
     const float4* tp = reinterpret_cast<const float4*>(s.triShade + h.gid); // one 128-byte line: positions, then attributes
     const float4 A = tp[0], B = tp[1], C = tp[2];
@@ -202,9 +204,22 @@ __device__ __forceinline__ Surface shade_surface(const SceneView& s, const Hit& 
         m.texNormal = __float_as_int(c2.z); m.texAlbedo = __float_as_int(c2.w); m.texRoughness = c3.x; m.texMetal = c3.y;
     }
 
+    const float u0 = s2.y, w0 = s2.z, u1 = s2.w, w1 = s3.x, u2 = s3.y, w2 = s3.z;
+    if (!full) {
+        Surface o;
+        o.normal = o.position = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+        o.roughness = o.metal = 0.0f;
+        o.albedo = mk4(m.albedo[0], m.albedo[1], m.albedo[2], m.albedo[3]);
+        if (needAlbedo && m.texAlbedo >= 0) {
+            const float u = u0 * h.b0 + u1 * h.b1 + u2 * h.b2;
+            const float v = w0 * h.b0 + w1 * h.b1 + w2 * h.b2;
+            o.albedo = tex2d_norm(mp->tex[1], u, v);
+        }
+        o.emission = mk4(m.emission[0], m.emission[1], m.emission[2], m.strength);
+        return o;
+    }
     const V4 e1 = mk4(B.x - A.x, B.y - A.y, B.z - A.z, 0.0f);
     const V4 e2 = mk4(C.x - A.x, C.y - A.y, C.z - A.z, 0.0f);
-    const float u0 = s2.y, w0 = s2.z, u1 = s2.w, w1 = s3.x, u2 = s3.y, w2 = s3.z;
     const float du1 = u1 - u0, dv1 = w1 - w0, du2 = u2 - u0, dv2 = w2 - w0;
     const float f = 1.0f / (du1 * dv2 - du2 * dv1);
     V4 tangent = mk4(f * (dv2 * e1.x - dv1 * e2.x), f * (dv2 * e1.y - dv1 * e2.y), f * (dv2 * e1.z - dv1 * e2.z), 0.0f);
@@ -315,7 +330,7 @@ __device__ __forceinline__ bool shade_segment(const RenderArgs& a, const Hit& h,
                                                __builtin_fmaxf(__builtin_fabsf(ray.oz), a.scene.sceneMaxAbs));
         if (!object_cull_pass(tmin, bfar, cullMax) || tmin > h.t + band_of(h.t, rayScale, a.scene.bandRel)) *cullFail = true;
     }
-    const Surface sf = shade_surface(a.scene, h, ho, hm, ht, matHint);
+    const Surface sf = shade_surface(a.scene, h, ho, hm, ht, matHint, i == 0 || i < a.bounceCount - 1, false);
     checksum += seg_hash(ho, hm, ht, sample, (uint32_t)i);
     if (i == 0 && sample == 0) { primary[0] = ho; primary[1] = hm; primary[2] = ht; }
 
@@ -933,6 +948,7 @@ __global__ __launch_bounds__(256) void wf_gen_kernel(const RenderArgs a, const W
 // the wave's share of finished lanes makes it worth leaving the traversal loops
 __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderArgs a, const WfBufs w, const int level, const int levels)
 {
+    __builtin_assume(level >= 1);   // the camera rays go through the packet kernel (launch_render_wf)
     __shared__ uint32_t ldsStack[kWfStack * kBlock];
     __shared__ uint32_t poolSlot[kBlock];
     __shared__ uint32_t wgCnt[8];
@@ -1096,6 +1112,7 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
 #endif
 __global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const RenderArgs a, const WfBufs w, const int level, const int levels)
 {
+    __builtin_assume(level == 0);   // launched for the camera rays only (launch_render_wf)
     __shared__ uint32_t wgCnt[8];
     const int lane = threadIdx.x & 63;
     LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
@@ -1448,6 +1465,7 @@ __global__ __launch_bounds__(256, DEAL ? RT_SHADE_OCC : RT_SHADE_OCC + 1) void w
 {
     __shared__ uint32_t wgCnt[8];
     LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
+    if (DEAL) __builtin_assume(level >= 1);   // launch_render_wf: <false> shades level 0, <true> the bounce levels
     if (!DEAL) { // queue order, one piece of 256 entries at a time
         const uint32_t piecesPerStripe = (w.subCap + 255u) / 256u;
         const uint32_t total = piecesPerStripe * kWfStripes;
@@ -1456,8 +1474,8 @@ __global__ __launch_bounds__(256, DEAL ? RT_SHADE_OCC : RT_SHADE_OCC + 1) void w
             const uint32_t cnt = *wf_count(w, level, (int)stripe);
             if (off - threadIdx.x >= cnt) continue; // uniform per workgroup
             ShadeOut o; // per entry: nothing of it lives across the loop's back edge
-            shade_entry(a, w, level, stripe, off, off < cnt, st, o);
-            shade_append(w, level, stripe, o);
+            shade_entry(a, w, 0, stripe, off, off < cnt, st, o);   // (this kernel is launched for level 0 only: a constant to the compiler)
+            shade_append(w, 0, stripe, o);
         }
     } else {
         constexpr uint32_t kBatchEntries = kShadeBatch * 256u;
