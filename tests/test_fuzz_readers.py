@@ -55,6 +55,31 @@ def test_damaged_images_and_obj(fuzzer, tmp_path):
     assert decoded > 0 and refused > 0
 
 
+def test_damaged_pngs_of_every_kind(fuzzer, tmp_path):
+    """Seeds for the paths of the PNG reader that the files above do not reach: packed 1 / 2 / 4-bit samples, 16 bits, palettes
+    with a tRNS, colour keys, gray + alpha, Adam7 (odd sizes, so that some passes are empty)."""
+    from test_texture_decode import write_png
+    rng = np.random.default_rng(1)
+    h, w = 13, 21
+    names = []
+
+    def add(name, *a, **k):
+        write_png(str(tmp_path / name), *a, **k)
+        names.append(name)
+    pal = rng.integers(0, 256, (16, 3))
+    for il in (False, True):
+        t = "i" if il else "n"
+        for d in (1, 2, 4):
+            add(f"g{d}{t}.png", rng.integers(0, 1 << d, (h, w)), d, interlace=il)
+            add(f"p{d}{t}.png", rng.integers(0, min(16, 1 << d), (h, w)), d, palette=pal[:min(16, 1 << d)], trns=bytes([0, 128, 255][:min(3, 1 << d)]), interlace=il)
+        add(f"g16{t}.png", rng.integers(0, 65536, (h, w)), 16, trns=(1234).to_bytes(2, "big"), interlace=il)
+        add(f"ga8{t}.png", rng.integers(0, 256, (h, w, 2)), 8, interlace=il)
+        add(f"rgb8k{t}.png", rng.integers(0, 4, (h, w, 3)) * 85, 8, trns=b"\x00\x55\x00\xaa\x00\xff", interlace=il)
+        add(f"rgba16{t}.png", rng.integers(0, 65536, (h, w, 4)), 16, interlace=il)
+    decoded, refused = run(fuzzer, 150, [str(tmp_path / n) for n in names])
+    assert decoded > 0 and refused > 0
+
+
 @pytest.mark.skipif(not os.path.isdir(REF_RES), reason="needs the reference checkout (its model files are the seeds)")
 def test_damaged_reference_models(fuzzer, tmp_path):
     files = []
