@@ -19,9 +19,9 @@ constexpr int kLeafMax = RT_LEAF_MAX;        // triangles per BVH leaf
 constexpr int kStackDepth = 128;   // exact kernels: up to 3 pushes per level of the four-wide tree
 constexpr int kLdsStack = 32;      // entries per lane kept in LDS; deeper entries spill to scratch
 #ifndef RT_WF_STACK
-#define RT_WF_STACK 32
+#define RT_WF_STACK 28
 #endif
-constexpr int kWfStack = RT_WF_STACK; // LDS stack entries per lane in wf_trace (overflow -> redo): 32 KB per workgroup
+constexpr int kWfStack = RT_WF_STACK; // LDS stack entries per lane in wf_trace (overflow -> redo): 28 KB per workgroup + 9 KB of ray pool (30 entries: one workgroup per CU less, measured)
 constexpr int kBlock = 256;        // workgroup size of every tracing kernel
 constexpr int kCounterSlots = 256; // statistics counters are striped over this many 128-byte lines
 constexpr int kCounterStride = 16; // u64 per slot

@@ -525,6 +525,7 @@ __global__ __launch_bounds__(256, 3) void path_kernel(const RenderArgs a)
     PathAcc acc; acc.ox = acc.oy = acc.oz = 0.0f; acc.bx = acc.by = acc.bz = 1.0f;
     Ray ray; ray.ox = ray.oy = ray.oz = ray.dx = ray.dy = ray.dz = 0.0f; ray.maxDist = 0.0f;
     Trav T; trav_begin(T, a.scene, ray, stack); T.node = kTravEnd;
+    uint32_t uNodes = 0, uTris = 0;   // wave-uniform statistics of the traversal bursts
     const uint32_t spp = a.sampleCount;
 
     for (;;) {
@@ -656,7 +657,8 @@ __global__ __launch_bounds__(256, 3) void path_kernel(const RenderArgs a)
 #ifdef RT_PHASE_TIMERS
         const long long tp1 = clock64();
 #endif
-        if (running) trav_burst(T, a.scene, ray, stack, st.bvh, (nRun * kKeepNum + kKeepDen - 1) / kKeepDen);
+        (void)running;
+        trav_burst(T, a.scene, ray, stack, st.bvh, (nRun * kKeepNum + kKeepDen - 1) / kKeepDen, uNodes, uTris);
 #ifdef RT_PHASE_TIMERS
         // diagnostic build: wave cycles outside / inside the traversal burst (reported through the idle-lane slots, /64)
         // slots: idleA burst, idleB shade, diagA pool, diagB raygen (all /64); slow = main-loop iterations
@@ -667,6 +669,7 @@ __global__ __launch_bounds__(256, 3) void path_kernel(const RenderArgs a)
         }
 #endif
     }
+    if (lane == 0) { st.bvh.nodes += uNodes; st.bvh.tris += uTris; }
     flush_stats(a, st, wgCnt);
 }
 
@@ -951,15 +954,19 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
     __builtin_assume(level >= 1);   // the camera rays go through the packet kernel (launch_render_wf)
     __shared__ uint32_t ldsStack[kWfStack * kBlock];
     __shared__ uint32_t poolSlot[kBlock];
+    __shared__ float4 poolO[kBlock], poolD[kBlock];   // the block of rays being handed out (`cur` below), one entry per lane
     __shared__ uint32_t wgCnt[8];
     HotStackT<kWfStack> stack; stack.lds = ldsStack + threadIdx.x; stack.dropped = false;
     const int lane = threadIdx.x & 63;
     uint32_t* slotx = poolSlot + (threadIdx.x & ~63);
+    float4* curO = poolO + (threadIdx.x & ~63);
+    float4* curD = poolD + (threadIdx.x & ~63);
     LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
 
     // Work arrives in blocks of up to 64 consecutive queue entries of one stripe, claimed with one
-    // atomic.  Three blocks are in flight so that a refill never waits on memory: `cur` (in registers,
-    // handed out lane by lane), `nxt` (its loads issued at the previous promotion) and the pending
+    // atomic.  Three blocks are in flight so that a refill never waits on memory: `cur` (in LDS: eight
+    // registers less across the traversal loops, and a lane fetches its ray with two reads where it took seven
+    // cross-lane moves), `nxt` (in registers, its loads issued at the previous promotion) and the pending
     // claim (its atomic issued then too).  Measured before this: a third of the wave time of the
     // level's launch went into the dependent chain atomic -> queue entry -> ray at refill time.
     const uint32_t waveId = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -967,11 +974,12 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
     unsigned long long exhausted = 0ull, poolMask = 0ull;
     bool pendIssued = false, nxtHas = false, noMore = false, have = false;
     uint32_t pendC = 0;                 // lane 0: cursor value returned by the pending atomic
-    uint32_t cSlot = kWfHole, nSlot = kWfHole, cOff = 0, nOff = 0;   // nOff/cOff: hit-array position of the lane's entry
-    float4 cO = make_float4(0, 0, 0, 0), cD = cO, nO = cO, nD = cO;
+    uint32_t cBase = 0, nBase = 0, nCount = 0;   // wave-uniform: hit-array position of a block's first entry, entries in the block (no holes past the camera rays)
+    float4 nO = make_float4(0, 0, 0, 0), nD = nO;
     uint32_t hitPos = 0;
     Ray ray; ray.ox = ray.oy = ray.oz = ray.dx = ray.dy = ray.dz = 0.0f; ray.maxDist = 0.0f;
     Trav T; trav_begin(T, a.scene, ray, stack); T.node = kTravEnd;
+    uint32_t uNodes = 0, uTris = 0, uSlow = 0;   // wave-uniform statistics (scalar registers)
 
     // picks the next stripe that still has entries (wave-uniform); false when none is left.  The count
     // of the stripe in use stays cached: re-reading it would put a dependent fetch into every refill.
@@ -1010,9 +1018,9 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
         if (nxtHas) {
             const size_t p = wf_pos(w, level, stripe, off + (uint32_t)lane);
             const bool in = (uint32_t)lane < n;
-            nSlot = in ? 0u : kWfHole;   // no holes past the camera rays
+            nCount = n;
             if (in) { nO = wf_ray_origin(a, w, level, p); nD = w.rayD[p]; }
-            nOff = (uint32_t)wf_hit_pos(w, stripe, off + (uint32_t)lane);
+            nBase = (uint32_t)wf_hit_pos(w, stripe, off);
             issue_claim();
         }
     };
@@ -1024,16 +1032,17 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
         const long long tq0 = clock64();
 #endif
         // ---- results of the lanes that finished
+        bool inBand = false;
         if (have && !trav_running(T)) {
             // a hit of another object inside the tie band, or a dropped stack entry: the hit record carries kWfDanger and
             // wf_shade sends the SAMPLE to the redo launch, which traces its path again with the exact in-order emulation
             // inline (1e-5 of the rays on C2, 2e-3 on C4, 7e-4 on C5).  RT_EXACT_PASS = 1 instead lists the tie-band rays and
             // traces them again between the level's trace and shade launches (wf_exact: one more launch per level)
             bool band = false;
-            const Hit h = trav_result(T, ray, band, a.scene.bandRel);
+            const Hit h = trav_result(T, a.scene, ray, band);
             const bool over = stack.dropped;
             stack.dropped = false;
-            if (band) st.slow++;
+            inBand = band;
 #if RT_EXACT_PASS
             if (band) { // listed under the stripe the ray sits in: that list cannot overflow
                 const uint32_t bs = hitPos / w.subCap;
@@ -1045,16 +1054,19 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
             w.hitM[hitPos] = make_uint2((h.gid == kNoHit ? kWfMiss : h.gid) | (over || band ? kWfDanger : 0u), T.bestObj);
             have = false;
         }
+        uSlow += (uint32_t)__popcll(__ballot(inBand));
 #ifdef RT_PHASE_TIMERS
         const long long tq1 = clock64();
 #endif
         // ---- refill from the pool
         unsigned long long need = __ballot(!have && !noMore);
+        bool fresh = false;   // the lane took a ray: its traversal is set up once, behind the loop (inside it the whole traversal
+                              // state would have to be merged at every turn: ninety register copies per refill)
         while (need != 0ull) {
             if (poolMask == 0ull) {
                 if (!nxtHas) { noMore = true; break; }
-                cSlot = nSlot; cO = nO; cD = nD; cOff = nOff;
-                poolMask = __ballot(cSlot != kWfHole);
+                curO[lane] = nO; curD[lane] = nD; cBase = nBase;
+                poolMask = nCount >= 64u ? ~0ull : (1ull << nCount) - 1ull;
                 load_next();
                 if (poolMask == 0ull) continue;
             }
@@ -1067,20 +1079,18 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
             __builtin_amdgcn_wave_barrier();
             const int src = (want && rank < avail) ? (int)slotx[rank] : lane;
             __builtin_amdgcn_wave_barrier();
-            const float ox = __shfl(cO.x, src), oy = __shfl(cO.y, src), oz = __shfl(cO.z, src), om = __shfl(cO.w, src);
-            const float dx = __shfl(cD.x, src), dy = __shfl(cD.y, src), dz = __shfl(cD.z, src);
-            const uint32_t hp = (uint32_t)__shfl((int)cOff, src);
             if (want && rank < avail) {
-                ray.ox = ox; ray.oy = oy; ray.oz = oz; ray.maxDist = om; ray.dx = dx; ray.dy = dy; ray.dz = dz;
-                hitPos = hp;
-                trav_begin(T, a.scene, ray, stack);
-                have = true;
+                const float4 o = curO[src], d = curD[src];
+                ray.ox = o.x; ray.oy = o.y; ray.oz = o.z; ray.maxDist = o.w; ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
+                hitPos = cBase + (uint32_t)src;
+                have = true; fresh = true;
             }
             // the entries handed out are the pool's first popc(taken) live ones
             const int taken = __popcll(__ballot(want && rank < avail));
             poolMask = __ballot(((poolMask >> lane) & 1ull) && __popcll(poolMask & below) >= taken);
             need = __ballot(!have && !noMore);
         }
+        if (fresh) trav_begin(T, a.scene, ray, stack);
         if (__ballot(have) == 0ull) break;
         // ---- traversal burst
         const bool running = have && trav_running(T);
@@ -1088,7 +1098,7 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
 #ifdef RT_PHASE_TIMERS
         const long long tq2 = clock64();
 #endif
-        if (running) trav_burst(T, a.scene, ray, stack, st.bvh, noMore ? 1 : (nRun * kKeepNum + kKeepDen - 1) / kKeepDen);
+        trav_burst(T, a.scene, ray, stack, st.bvh, noMore ? 1 : (nRun * kKeepNum + kKeepDen - 1) / kKeepDen, uNodes, uTris);
 #ifdef RT_PHASE_TIMERS
         if (lane == 0) {
             st.bvh.idleA += (uint32_t)((clock64() - tq2) >> 6); st.bvh.idleB += (uint32_t)((tq1 - tq0) >> 6);
@@ -1096,6 +1106,7 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
         }
 #endif
     }
+    if (lane == 0) { st.bvh.nodes += uNodes; st.bvh.tris += uTris; st.slow += uSlow; }
     flush_stats(a, st, wgCnt);
 }
 
@@ -1230,7 +1241,7 @@ __global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const R
                         const float4* tp = reinterpret_cast<const float4*>(a.scene.triLeaf + T.triBase + first + q);
                         const float4 A = tp[0], B = tp[1], C = tp[2];
                         st.bvh.tris += active ? 1u : 0u;
-                        trav_test_triangle(T, A, B, C, a.scene.bandRel);
+                        trav_test_triangle(T, a.scene, A, B, C);
                     }
                     if (sp == 0) break;
                     node = __builtin_amdgcn_readlane((int)stk, --sp);
@@ -1242,7 +1253,7 @@ __global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const R
 #endif
         if (active) {
             bool band = false;
-            const Hit hres = trav_result(T, ray, band, a.scene.bandRel);
+            const Hit hres = trav_result(T, a.scene, ray, band);
             const uint32_t hitPos = (uint32_t)wf_hit_pos(w, blockStripe, off + (uint32_t)lane);
             if (band) st.slow++;
 #if RT_EXACT_PASS

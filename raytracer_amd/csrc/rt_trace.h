@@ -719,7 +719,7 @@ struct Trav {
     int32_t node;
     uint32_t triFirst, triCount, triBase;
     int sp;
-    float bound, m0, rayScale;
+    float bound, m0;
     Hit best;
     uint32_t bestObj;
     float otherT;
@@ -727,13 +727,18 @@ struct Trav {
     TriRay q;
     BoxRay br;
 };
+// scale of the tie band: the largest |coordinate| of the ray origin or the scene -- from the rotated origin the triangle test
+// keeps (the same three values in another order; max is exact), so that no register holds it across the loops
+__device__ __forceinline__ float trav_ray_scale(const Trav& T, const SceneView& s)
+{
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(T.q.pox), __builtin_fabsf(T.q.poy)),
+                           __builtin_fmaxf(__builtin_fabsf(T.q.poz), s.sceneMaxAbs));
+}
 // per-ray part of the state (everything but the lane's position in the tree)
 __device__ __forceinline__ void trav_init(Trav& T, const SceneView& s, const Ray& ray)
 {
     T.q = make_tri_ray(ray);
     T.br = make_box_ray(ray, s.sceneMaxAbs);
-    T.rayScale = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ray.ox), __builtin_fabsf(ray.oy)),
-                                 __builtin_fmaxf(__builtin_fabsf(ray.oz), s.sceneMaxAbs));
     T.m0 = ray.maxDist; T.bound = ray.maxDist;
     T.best.t = FLT_MAX; T.best.gid = kNoHit; T.best.b0 = T.best.b1 = T.best.b2 = 0.0f;
     T.bestObj = kNoHit; T.otherT = FLT_MAX;
@@ -768,7 +773,7 @@ __device__ __forceinline__ void trav_take_leaf(Trav& T, const SceneView& s, HS& 
 // The object-space cull of the winner's object (GPURaytracer.cu:267-315) is checked once, by the
 // shading side: a hit on an object whose cull fails (flat meshes) sends the pixel to the
 // redo launch instead of costing every triangle step a 96-byte fetch and a slab test.
-__device__ __forceinline__ void trav_test_triangle(Trav& T, const float4& A, const float4& B, const float4& C, const float bandRel)
+__device__ __forceinline__ void trav_test_triangle(Trav& T, const SceneView& s, const float4& A, const float4& B, const float4& C)
 {
     float t, b0, b1, b2;
     if (tri_test_rot(T.q, T.m0, A, B, C, t, b0, b1, b2) && t <= T.bound) {
@@ -781,7 +786,7 @@ __device__ __forceinline__ void trav_test_triangle(Trav& T, const float4& A, con
         T.bestObj = better ? obj : T.bestObj;
         T.best.t = better ? t : T.best.t; T.best.b0 = better ? b0 : T.best.b0; T.best.b1 = better ? b1 : T.best.b1;
         T.best.b2 = better ? b2 : T.best.b2; T.best.gid = better ? gid : T.best.gid;
-        T.bound = better ? __builtin_fminf(T.m0, t + band_of(t, T.rayScale, bandRel)) : T.bound;
+        T.bound = better ? __builtin_fminf(T.m0, t + band_of(t, trav_ray_scale(T, s), s.bandRel)) : T.bound;
     }
 }
 
@@ -791,9 +796,8 @@ __device__ __forceinline__ void trav_tri_step(Trav& T, const SceneView& s, const
     if (T.triCount != 0u) {
         const float4* p = reinterpret_cast<const float4*>(s.triLeaf + T.triFirst);
         const float4 A = p[0], B = p[1], C = p[2];
-        T.triFirst++; T.triCount--;
-        cnt.tris++;
-        trav_test_triangle(T, A, B, C, s.bandRel);
+        T.triFirst++; T.triCount--;   // (counted by trav_burst, from the vote)
+        trav_test_triangle(T, s, A, B, C);
     }
     trav_take_leaf(T, s, stack);
 }
@@ -802,11 +806,13 @@ __device__ __forceinline__ void trav_tri_step(Trav& T, const SceneView& s, const
 #define RT_TRI_NUM 4
 #endif
 #define RT_TRI_DEN 4
-// Runs traversal steps for the calling lanes (all of them still traversing) until fewer than
-// `keep` of them remain; the others wait at the reconvergence point with their result.
+// Runs traversal steps until fewer than `keep` lanes of the wave are still traversing; the others wait with their result.
+// Called by every lane of the wave: a lane without an unfinished query (trav_running false) wants no step and idles, so the
+// loop control and the statistics -- node and triangle tests counted per step from the votes, into wave-uniform sums that
+// live in scalar registers -- are the same for all lanes.
 template <class HS>
 __device__ __forceinline__ void trav_burst(Trav& T, const SceneView& s, const Ray& ray, HS& stack,
-                                           BvhCounters& cnt, int keep)
+                                           BvhCounters& cnt, int keep, uint32_t& uNodes, uint32_t& uTris)
 {
 #ifdef RT_LOOP_TIMERS
     const bool leader = (int)(threadIdx.x & 63) == __builtin_ctzll(__ballot(true));
@@ -821,6 +827,7 @@ __device__ __forceinline__ void trav_burst(Trav& T, const SceneView& s, const Ra
         // leave when most of the wave has finished: the finished lanes get shaded and re-armed
         if (__popcll(__ballot(wantNode || wantTri)) < keep || nNode + nTri == 0) break;
         if (nTri * RT_TRI_DEN >= nNode * RT_TRI_NUM) {
+            uTris += (uint32_t)__popcll(__ballot(T.triCount != 0u));
             if (wantTri) {
                 count_idle(cnt.idleB);
 #ifdef RT_LOOP_TIMERS
@@ -832,8 +839,8 @@ __device__ __forceinline__ void trav_burst(Trav& T, const SceneView& s, const Ra
             if (leader) cnt.idleB += (uint32_t)((clock64() - tl0) >> 4);
 #endif
         } else {
+            uNodes += (uint32_t)nNode;
             if (wantNode) {
-                cnt.nodes++;
                 count_idle(cnt.idleA);
 #ifdef RT_LOOP_TIMERS
                 if ((int)(threadIdx.x & 63) == __builtin_ctzll(__ballot(true))) cnt.diagA++;
@@ -849,10 +856,10 @@ __device__ __forceinline__ void trav_burst(Trav& T, const SceneView& s, const Ra
 }
 
 // Closest hit of a finished traversal; `danger` = another object has a hit inside the tie band.
-__device__ __forceinline__ Hit trav_result(const Trav& T, Ray& ray, bool& danger, const float bandRel)
+__device__ __forceinline__ Hit trav_result(const Trav& T, const SceneView& s, Ray& ray, bool& danger)
 {
     if (T.best.gid != kNoHit) {
-        const float limit = T.best.t + band_of(T.best.t, T.rayScale, bandRel);
+        const float limit = T.best.t + band_of(T.best.t, trav_ray_scale(T, s), s.bandRel);
         if (T.otherT < FLT_MAX && T.otherT <= limit) danger = true;   // FLT_MAX = no other object hit (the limit may be infinite)
         ray.maxDist = T.best.t;
     }
@@ -864,9 +871,9 @@ __device__ __forceinline__ Hit trav_finish(Trav& T, const SceneView& s, Ray& ray
 {
     if (T.best.gid != kNoHit) {
         cull_lookup(s, ray, T.bestObj, T.cc);
-        if (!object_cull_pass(T.cc.tmin, T.cc.bfar, T.m0) || T.cc.tmin > T.best.t + band_of(T.best.t, T.rayScale, s.bandRel)) danger = true;   // see trace_bvh on the second test
+        if (!object_cull_pass(T.cc.tmin, T.cc.bfar, T.m0) || T.cc.tmin > T.best.t + band_of(T.best.t, trav_ray_scale(T, s), s.bandRel)) danger = true;   // see trace_bvh on the second test
     }
-    return trav_result(T, ray, danger, s.bandRel);
+    return trav_result(T, s, ray, danger);
 }
 
 } // namespace rt
