@@ -212,11 +212,12 @@ int rt_render_noalloc(rt_ctx* ctx, const rt_camera_params* camera, const rt_rend
  * (object, mesh, triangle, float bits of t; all 0xFFFFFFFF on miss).  Host pointers.
  * Exact in every traversal mode, including the reference's order-dependent cases: ties between objects, hits that lie
  * before their object's bounding-box entry, and the noise hits its triangle test reports on triangles of no area
- * (collinear vertices), which no bounding box can stand for.  rt_render gives the same pixels as
- * the reference in all of these; in the last, camera rays are tested against the listed lines where they are made and
- * take the exact walks when they come near, while bounce rays (directions out of the RNG) rely on not passing within
- * ~1e-7 of such a triangle's line (measured: never in 2e8 rays on the reference's sword); RT_OPT_TRAVERSAL = 1 removes
- * that reliance at brute-force cost. */
+ * (collinear vertices), which the triangle's own bounding box does not stand for.  rt_render gives
+ * the same pixels as the reference in all of these, by construction: the box the tree holds for a sliver is grown by what
+ * the rounding noise can displace the reported hit (the whole length for a collinear triangle), so every walk reaches the
+ * test whose answer the reference reports, for camera and bounce rays alike; camera rays, which may start far outside the
+ * scene's bounds, are also tested against the listed lines where they are made and take the exact walks when they come
+ * near. */
 int rt_trace_rays(rt_ctx* ctx, const float* rays, int32_t nRays, uint32_t* out);
 
 /* HIP-event timing on the context stream: record into slot 0..13, elapsed between two slots

@@ -150,6 +150,45 @@ __device__ __forceinline__ void tri_box(const TriIsect& t, float* mn, float* mx)
     mn[2] = __builtin_fminf(t.v0z, __builtin_fminf(t.v1z, t.v2z)); mx[2] = __builtin_fmaxf(t.v0z, __builtin_fmaxf(t.v1z, t.v2z));
 }
 
+// The box a walk of the tree may prune a triangle by.  For a well-shaped triangle that is its bounding box.  For a sliver it
+// is not.  The reference's test (GPURaytracer.cu:551-637) reports t = sum b_i z_i with b_i = e_i / det >= 0 (it rejects mixed
+// signs) and z_i = the ray parameter at which the ray reaches vertex i's coordinate along its dominant axis, so t always lies
+// in the box's slab along THAT axis.  But the b_i carry the rounding noise of the edge functions: the sheared vertex
+// offsets are good to ~6 * 2^-24 D (D = the largest coordinate difference between the ray's origin and the vertices), an
+// edge function over a triangle of length L to ~2^-20.4 D L, against det = w L for a triangle of altitude w (both seen in
+// projection along the ray, which cancels).  The point of the ray at the reported t is therefore displaced ALONG the ray from
+// where it crosses the triangle, by up to that share of the slab's length, and leaves the box sideways by up to
+//     L min(1, 2^-20.4 D / w)
+// (for a collinear triangle, w = 0, the b_i are all noise and t is anywhere in the slab: the whole length).  A walk that has
+// found something nearer in between would prune the box and never run the test whose answer the reference reports
+// (thin_kernel below tells how this was found).  So the box a walk sees grows on every side by that amount with D = 2 S
+// (S = the scene's largest |coordinate|: a bounce ray starts on a surface of the scene), less the three quarters of the
+// ray-side pad of the box test (2^-18 S on every side of every box, make_box_ray) that the box test's own rounding leaves
+// unused: nothing for a triangle up to ~4 times as long as it is high, the whole length for a collinear one.  With that
+// every traversal finds every hit the reference reports for any ray that starts inside the scene's bounds, by construction
+// (tests/thin_scene.py passes with the camera-ray test of wf_gen compiled out, which it did not before); camera rays, which
+// may start far outside the bounds, are in addition tested against the listed lines where they are made (wf_gen).
+__device__ __forceinline__ void tri_box_walk(const TriIsect& t, float S, float* mn, float* mx)
+{
+    tri_box(t, mn, mx);
+#if defined(RT_DIAG_NO_THIN_ALL) && RT_DIAG_NO_THIN_ALL == 2   // diagnostic build: neither the listed-line tests nor this (what the soak then finds)
+    return;
+#endif
+    const float ax = t.v1x - t.v0x, ay = t.v1y - t.v0y, az = t.v1z - t.v0z;
+    const float bx = t.v2x - t.v0x, by = t.v2y - t.v0y, bz = t.v2z - t.v0z;
+    const float cx = t.v2x - t.v1x, cy = t.v2y - t.v1y, cz = t.v2z - t.v1z;
+    const float nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+    const float area2 = sqrtf(nx * nx + ny * ny + nz * nz);
+    const float L = sqrtf(fmaxf(fmaxf(ax * ax + ay * ay + az * az, bx * bx + by * by + bz * bz), cx * cx + cy * cy + cz * cz));
+    if (!(L > 0.0f) || !(L < FLT_MAX) || !(S > 0.0f)) return;   // no extent, or not finite: never hit
+    const float w = area2 / L;                                     // altitude on the longest edge
+    const float noise = 1.4453e-06f * S;                           // 2^-20.4 * 2 S
+    float r = !(w > noise) ? L : L * (noise / w);                  // NaN area -> L
+    r -= 2.86102294921875e-06f * S;                                // 3/4 of the ray-side pad
+    if (!(r > 0.0f)) return;
+    for (int a = 0; a < 3; a++) { mn[a] -= r; mx[a] += r; }
+}
+
 __global__ __launch_bounds__(256) void morton_kernel(const TriIsect* __restrict__ triRef, uint32_t nTris,
                                                      const uint32_t* __restrict__ bounds, MortonPlan plan,
                                                      unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals)
@@ -195,14 +234,14 @@ __global__ __launch_bounds__(256) void morton_kernel(const TriIsect* __restrict_
 // triangle of altitude w seen from up to 2 S away (S = the scene's largest |coordinate|) that needs w < 2^-20 S.  Triangles
 // with altitude below 2^-17 S are listed here, as the line they lie on, and the walks of the exact paths (bvh_walk: every
 // rt_trace_rays query, the redo launches, wf_exact) test them after the tree, behind a cheap test of the ray's distance to that
-// line (rt_trace.h, thin_near).  Camera rays -- the rays a scene can aim at such a line by construction -- are tested against
-// every listed line where they are made (wf_gen, path_kernel) and sent to the exact walks when they come near
-// (tests/thin_scene.py aims them on purpose; the test fails without it).  Bounce rays are not: their directions come out of
-// the RNG, and one passing within ~1e-7 of a given line was not seen in 200 M rays of a C3 frame (tools/thin_check.py), while
-// looking out for it in wf_shade cost C3 a fifth of its frame time.  RT_OPT_TRAVERSAL = 1 is there for a caller who needs
-// the guarantee for those too.  The triangles stay in the tree as well (testing one twice changes nothing).  A
-// triangle of no extent at all, or with a vertex that is not finite, is never hit (all three edge functions are exactly 0,
-// or NaN) and is not listed.
+// line (rt_trace.h, thin_near).  Camera rays -- the rays a scene can aim at such a line by construction, from any distance --
+// are tested against every listed line where they are made (wf_gen, path_kernel) and sent to the exact walks when they come
+// near (tests/thin_scene.py aims them on purpose).  Since round 3 the tree itself also stands for these triangles: the box a
+// walk sees for a sliver is grown by what the noise can displace the reported hit (tri_box_walk above: the whole length for
+// a collinear triangle), so that every walk -- the hot kernels' too, for camera and bounce rays alike -- reaches the test
+// whose answer the reference reports; the listed-line tests stay as the cover for rays that start far outside the scene's
+// bounds.  The triangles stay in the tree as well (testing one twice changes nothing).  A triangle of no extent at all, or
+// with a vertex that is not finite, is never hit (all three edge functions are exactly 0, or NaN) and is not listed.
 __global__ __launch_bounds__(256) void thin_kernel(const TriIsect* __restrict__ triRef, uint32_t nTris, float tau,
                                                    uint32_t* __restrict__ count, ThinTri* __restrict__ list)
 {
@@ -228,13 +267,13 @@ __global__ __launch_bounds__(256) void thin_kernel(const TriIsect* __restrict__ 
 
 // boxes of the triangles in sorted (Morton) order: "node" N-1+j of the binary tree is sorted triangle j
 __global__ __launch_bounds__(256) void leafbox_kernel(const TriIsect* __restrict__ triRef, const uint32_t* __restrict__ order,
-                                                      uint32_t nTris, float* __restrict__ boxes)
+                                                      uint32_t nTris, float sceneMaxAbs, float* __restrict__ boxes)
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nTris) return;
     const TriIsect t = triRef[order[j]];
     float mn[3], mx[3];
-    tri_box(t, mn, mx);
+    tri_box_walk(t, sceneMaxAbs, mn, mx);
     float* b = boxes + 6 * (size_t)(nTris - 1 + j);
     b[0] = mn[0]; b[1] = mn[1]; b[2] = mn[2]; b[3] = mx[0]; b[4] = mx[1]; b[5] = mx[2];
 }
@@ -639,7 +678,7 @@ __global__ __launch_bounds__(256) void regather_kernel(const TriIsect* __restric
 // the boxes the level below has just written (float boxes kept beside the nodes for the duration: fitting from the decoded
 // 8-bit planes would widen every level by its rounding), then the node is encoded as the collapse encodes it.
 __global__ __launch_bounds__(256) void refit_level_kernel(BvhNode* __restrict__ nodes, float* __restrict__ nodeBox,
-                                                          const TriIsect* __restrict__ triWorld, uint32_t begin, uint32_t end)
+                                                          const TriIsect* __restrict__ triWorld, float sceneMaxAbs, uint32_t begin, uint32_t end)
 {
     const uint32_t i = begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= end) return;
@@ -662,7 +701,7 @@ __global__ __launch_bounds__(256) void refit_level_kernel(BvhNode* __restrict__ 
             b[0] = b[1] = b[2] = FLT_MAX; b[3] = b[4] = b[5] = -FLT_MAX;
             for (uint32_t t = 0; t < cnt; t++) {
                 float mn[3], mx[3];
-                tri_box(triWorld[first + t], mn, mx);
+                tri_box_walk(triWorld[first + t], sceneMaxAbs, mn, mx);
 #pragma unroll
                 for (int a = 0; a < 3; a++) { b[a] = __builtin_fminf(b[a], mn[a]); b[3 + a] = __builtin_fmaxf(b[3 + a], mx[a]); }
             }
@@ -874,7 +913,7 @@ bool build_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
     // from here on: valsB = sorted order, keysB = sorted keys; keysA and valsA are free
     uint32_t* pos = (uint32_t*)keysA;      // final leaf slot of sorted triangle j (written by the collapse)
 
-    hipLaunchKernelGGL(leafbox_kernel, dim3(grid), dim3(256), 0, stream, out.triRef, valsB, nTris, boxes);
+    hipLaunchKernelGGL(leafbox_kernel, dim3(grid), dim3(256), 0, stream, out.triRef, valsB, nTris, maxAbs, boxes);
     RT_HIPC(hipGetLastError());
 
     if (nTris == 1) {
@@ -1030,7 +1069,7 @@ bool refit_scene(const Segment* dSegs, int nSegs, const ObjXform* dXf, uint32_t 
         const uint32_t b = out.levelBegin[L], e = out.levelBegin[L + 1];
         if (e <= b) continue;
         hipLaunchKernelGGL(refit_level_kernel, dim3((e - b + 255) / 256), dim3(256), 0, stream, out.nodes, out.sBoxes,
-                           out.triLeaf + 2 * (size_t)nTris, b, e);
+                           out.triLeaf + 2 * (size_t)nTris, maxAbs, b, e);
     }
     RT_HIP(hipGetLastError());
     RT_HIP(hipMemsetAsync(out.sArea, 0, sizeof(float), stream));

@@ -127,6 +127,9 @@ struct SceneView {
 // One slot per sample of a chunk of 8x8 pixel tiles: slot = pixelInChunk * spp + sampleIndex.
 // Per bounce level L a queue lists the slots whose path is still alive; it is cut into kWfStripes
 // sub-queues with their own counts and cursors (a single hot counter saturates at ~88 atomics/us).
+#ifdef RT_DIAG_NO_THIN_ALL   // diagnostic build: no listed-line test anywhere (camera rays, exact walks)
+#define RT_DIAG_NO_THIN_GEN 1
+#endif
 #ifndef RT_EXACT_PASS
 #define RT_EXACT_PASS 1   // 1: the tie-band rays of a level are listed and traced again by wf_exact before the level is shaded;
 #endif                    // 0: every tie-band ray sends its sample to the redo launch instead (four launches per frame fewer, whole paths redone)

@@ -1034,10 +1034,11 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
         // ---- results of the lanes that finished
         bool inBand = false;
         if (have && !trav_running(T)) {
-            // a hit of another object inside the tie band, or a dropped stack entry: the hit record carries kWfDanger and
-            // wf_shade sends the SAMPLE to the redo launch, which traces its path again with the exact in-order emulation
-            // inline (1e-5 of the rays on C2, 2e-3 on C4, 7e-4 on C5).  RT_EXACT_PASS = 1 instead lists the tie-band rays and
-            // traces them again between the level's trace and shade launches (wf_exact: one more launch per level)
+            // A hit of another object inside the tie band (1e-5 of the rays on C2, 2e-3 on C4, 7e-4 on C5): the ray is listed
+            // for wf_exact, which traces it again with the reference's in-order semantics between this launch and the level's
+            // shade launch (RT_EXACT_PASS = 1, the default).  A dropped stack entry -- and, in a build with RT_EXACT_PASS = 0, the
+            // tie band too -- marks the hit record with kWfDanger: wf_shade then sends the SAMPLE to the redo launch, which
+            // traces its whole path again with the exact emulation inline and a full-depth stack.
             bool band = false;
             const Hit h = trav_result(T, a.scene, ray, band);
             const bool over = stack.dropped;

@@ -471,6 +471,7 @@ __device__ __forceinline__ void bvh_walk(const SceneView& s, const Ray& ray, con
         }
     }
     // the triangles no box can stand for (rt_commit.hip, thin_kernel): a handful at most in a sane scene, none in most
+#ifndef RT_DIAG_NO_THIN_ALL   // diagnostic build: the grown boxes of the tree alone (rt_commit.hip, tri_box_walk)
     for (uint32_t k = 0; k < s.nThin; k++) {
         const ThinTri r = s.thin[k];
         if (!thin_near(r, ray)) continue;
@@ -479,6 +480,7 @@ __device__ __forceinline__ void bvh_walk(const SceneView& s, const Ray& ray, con
         cnt.tris++;
         bound = visit(A, B, C, bound);
     }
+#endif
 }
 
 struct CullCache {
