@@ -107,6 +107,10 @@ enum rt_option {
                              unless the refitted boxes sum to more than 1.3 times the built tree's area (the next frames
                              would then lose to the looser boxes what the commit saved, and the tree is built anew); 0: every commit builds;
                              101 ...: that limit in percent.  Same pixels either way. */
+    RT_OPT_THIN_LIST = 9, /* 1 (default): camera rays and the exact walks are tested against the listed lines of the scene's
+                             collinear triangles; 0: those tests are off and the grown sliver boxes of
+                             the tree stand alone -- a diagnostic, for the test that shows they do for rays that start inside
+                             the scene's bounds. */
     RT_OPT_WF_LANE = 7    /* frames in flight: the workspace lane (0 .. 3, default 0) the following rt_render / rt_render_bands
                              calls use first.  Two calls that use different lanes AND run on different streams (rt_set_stream)
                              may overlap on the GPU -- frame i + 1 fills the machine while frame i's last rays finish, which is

@@ -65,7 +65,7 @@ EXPORTS = [
     "rt_image_load", "rt_image_free", "rt_render", "rt_render_bands", "rt_render_noalloc", "rt_trace_rays", "rt_event_record", "rt_event_elapsed_ms", "rt_detmath_eval", "rt_version",
 ]
 
-OPT_TRAVERSAL, OPT_COUNTERS, OPT_ACCUMULATE_STATS, OPT_WF_CHUNK, OPT_WF_LANES, OPT_BUILDER, OPT_WF_LANE, OPT_REFIT = 1, 2, 3, 4, 5, 6, 7, 8
+OPT_TRAVERSAL, OPT_COUNTERS, OPT_ACCUMULATE_STATS, OPT_WF_CHUNK, OPT_WF_LANES, OPT_BUILDER, OPT_WF_LANE, OPT_REFIT, OPT_THIN_LIST = 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 
 def lib():

@@ -79,6 +79,7 @@ struct rt_ctx {
     std::vector<rt::Segment> builtSegs; uint64_t builtEpoch = 0, meshEpoch = 0; int builtBuilder = 0; bool builtValid = false;
     int commitKind = 0;                       // last rt_scene_commit: 1 = full build, 2 = refit
     int optRefit = kRefitGrowthDefault;       // 0 = never refit; else the growth limit in percent
+    int optThinList = 1;                      // 0: the listed-line tests of the collinear triangles are off (diagnostic)
     rt::Segment* dSegs = nullptr; rt::ObjXform* dXf = nullptr;
     size_t capObjectsBytes = 0, capMaterialsBytes = 0, capSegsBytes = 0, capXfBytes = 0;
     rt::ObjCull* dObjects = nullptr; uint32_t nObjects = 0;
@@ -266,7 +267,7 @@ rt::SceneView scene_view(const rt_ctx* c)
     s.rootIsValid = c->built.nTris > 0 ? 1 : 0;
     s.sceneMaxAbs = c->built.sceneMaxAbs;
     s.bandRel = c->bandRel;
-    s.thin = c->built.thin; s.nThin = c->built.nThin;
+    s.thin = c->built.thin; s.nThin = c->optThinList ? c->built.nThin : 0u;
     return s;
 }
 
@@ -475,6 +476,9 @@ int rt_set_option(rt_ctx* c, int option, int value)
     case RT_OPT_REFIT:
         if (value < 0 || (value > 1 && value <= 100)) return fail(c, RT_ERR_INVALID, "RT_OPT_REFIT takes 0 (off), 1 (default limit) or a growth limit in percent above 100");
         c->optRefit = value == 1 ? kRefitGrowthDefault : value; return RT_OK;
+    case RT_OPT_THIN_LIST:
+        if (value < 0 || value > 1) return fail(c, RT_ERR_INVALID, "RT_OPT_THIN_LIST takes 0 or 1");
+        c->optThinList = value; return RT_OK;
     case RT_OPT_BUILDER:
         if (value < 0 || value > 1) return fail(c, RT_ERR_INVALID, "RT_OPT_BUILDER takes 0 (PLOC, default) or 1 (radix tree, fast rebuilds)");
         c->optBuilder = value; return RT_OK;

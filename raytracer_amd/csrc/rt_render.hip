@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256, 3) void path_kernel(const RenderArgs a)
         }
 #ifdef RT_PHASE_TIMERS
         const long long tpa = clock64();
-        const int nShade = __popcll(__ballot(true));
+        const int nShade = __popcll(rt_ballot(true));
 #endif
         // ---- (1a) lanes whose path ended: next sample of the pixel, or the pixel is finished
         if (hasPixel && !hasPath) {
@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256, 3) void path_kernel(const RenderArgs a)
             }
         }
         // ---- (1b) lanes without a pixel take one from the wave's pool
-        unsigned long long need = __ballot(!hasPixel && !noMore);
+        unsigned long long need = rt_ballot(!hasPixel && !noMore);
         while (need != 0ull) {
             if (poolMask == 0ull) {
                 int t = -1;
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256, 3) void path_kernel(const RenderArgs a)
                 poolX = a.x0 + (t % a.tiles8X) * 8;
                 poolY = a.y0 + (t / a.tiles8X) * 8;
                 const bool valid = poolX + (lane & 7) < a.x1 && poolY + (lane >> 3) < a.y1;
-                poolMask = __ballot(valid);
+                poolMask = rt_ballot(valid);
                 if (poolMask == 0ull) continue;
             }
             // the k-th needing lane takes the k-th free pixel of the tile
@@ -617,12 +617,12 @@ __global__ __launch_bounds__(256, 3) void path_kernel(const RenderArgs a)
                 pr = pg = pb = 0.0f; tr = tg = tb = 0.0f;
             }
             __builtin_amdgcn_wave_barrier();
-            const unsigned long long taken = __ballot(want && rank < avail);
+            const unsigned long long taken = rt_ballot(want && rank < avail);
             int k = __popcll(taken); // the bits handed out are the lowest popc(taken) set bits
             unsigned long long m = poolMask;
             while (k-- > 0) m &= m - 1ull;
             poolMask = m;
-            need = __ballot(!hasPixel && !noMore);
+            need = rt_ballot(!hasPixel && !noMore);
         }
 #ifdef RT_PHASE_TIMERS
         const long long tpc = clock64();
@@ -649,11 +649,11 @@ __global__ __launch_bounds__(256, 3) void path_kernel(const RenderArgs a)
                 pb += 1.0f - rtd::exp_f(-0.0f * a.exposure);
             }
         }
-        if (__ballot(hasPixel) == 0ull) break; // every lane is idle and no tile is left
+        if (rt_ballot(hasPixel) == 0ull) break; // every lane is idle and no tile is left
 
         // ---- (2) traversal burst for every lane with an unfinished query
         const bool running = hasPath && trav_running(T);
-        const int nRun = __popcll(__ballot(running));
+        const int nRun = __popcll(rt_ballot(running));
 #ifdef RT_PHASE_TIMERS
         const long long tp1 = clock64();
 #endif
@@ -1055,12 +1055,12 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
             w.hitM[hitPos] = make_uint2((h.gid == kNoHit ? kWfMiss : h.gid) | (over || band ? kWfDanger : 0u), T.bestObj);
             have = false;
         }
-        uSlow += (uint32_t)__popcll(__ballot(inBand));
+        uSlow += (uint32_t)__popcll(rt_ballot(inBand));
 #ifdef RT_PHASE_TIMERS
         const long long tq1 = clock64();
 #endif
         // ---- refill from the pool
-        unsigned long long need = __ballot(!have && !noMore);
+        unsigned long long need = rt_ballot(!have && !noMore);
         bool fresh = false;   // the lane took a ray: its traversal is set up once, behind the loop (inside it the whole traversal
                               // state would have to be merged at every turn: ninety register copies per refill)
         while (need != 0ull) {
@@ -1087,15 +1087,15 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
                 have = true; fresh = true;
             }
             // the entries handed out are the pool's first popc(taken) live ones
-            const int taken = __popcll(__ballot(want && rank < avail));
-            poolMask = __ballot(((poolMask >> lane) & 1ull) && __popcll(poolMask & below) >= taken);
-            need = __ballot(!have && !noMore);
+            const int taken = __popcll(rt_ballot(want && rank < avail));
+            poolMask = rt_ballot(((poolMask >> lane) & 1ull) && __popcll(poolMask & below) >= taken);
+            need = rt_ballot(!have && !noMore);
         }
         if (fresh) trav_begin(T, a.scene, ray, stack);
-        if (__ballot(have) == 0ull) break;
+        if (rt_ballot(have) == 0ull) break;
         // ---- traversal burst
         const bool running = have && trav_running(T);
-        const int nRun = __popcll(__ballot(running));
+        const int nRun = __popcll(rt_ballot(running));
 #ifdef RT_PHASE_TIMERS
         const long long tq2 = clock64();
 #endif
@@ -1175,7 +1175,7 @@ __global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const R
             ray.ox = o.x; ray.oy = o.y; ray.oz = o.z; ray.maxDist = o.w; ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
         }
         Trav T; trav_init(T, a.scene, ray); // a lane without a ray has bound -1: it enters no box and accepts no hit
-        if (__ballot(active) == 0ull) continue;
+        if (rt_ballot(active) == 0ull) continue;
         bool overflow = false;
 #ifdef RT_PHASE_TIMERS
         const long long tk1 = clock64();
@@ -1202,8 +1202,8 @@ __global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const R
                     dbgNodes++; dbgSp = sp > dbgSp ? sp : dbgSp;
 #endif
                     // children some lane enters, ordered by the entry distances of the first lane that enters any
-                    const unsigned long long h0 = __ballot(k[0] != kMissKey), h1 = __ballot(k[1] != kMissKey),
-                                             h2 = __ballot(k[2] != kMissKey), h3 = __ballot(k[3] != kMissKey);
+                    const unsigned long long h0 = rt_ballot(k[0] != kMissKey), h1 = rt_ballot(k[1] != kMissKey),
+                                             h2 = rt_ballot(k[2] != kMissKey), h3 = rt_ballot(k[3] != kMissKey);
                     const unsigned long long any = h0 | h1 | h2 | h3;
                     int h = 0;
                     if (any != 0ull) {
@@ -1450,7 +1450,7 @@ __device__ __forceinline__ void shade_entry(const RenderArgs& a, const WfBufs& w
 __device__ __forceinline__ void shade_append(const WfBufs& w, const int level, const uint32_t stripe, const ShadeOut& o)
 {
     const int lane = threadIdx.x & 63;
-    const unsigned long long mm = __ballot(o.more);
+    const unsigned long long mm = rt_ballot(o.more);
     if (mm == 0ull) return;
     uint32_t base = 0;
     if (lane == 0) base = atomicAdd(wf_count(w, level + 1, (int)stripe), (uint32_t)__popcll(mm));
@@ -1519,7 +1519,7 @@ __global__ __launch_bounds__(256, DEAL ? RT_SHADE_OCC : RT_SHADE_OCC + 1) void w
                 const bool isHit = in && ((g0 & kWfMiss) != kWfMiss || (g0 & kWfDanger) != 0u);   // no holes past the camera rays
                 const bool isMiss = false;
                 cls |= (isHit ? 1u : (isMiss ? 2u : 0u)) << (2u * j);
-                const unsigned long long hb = __ballot(isHit), mb = __ballot(isMiss);
+                const unsigned long long hb = rt_ballot(isHit), mb = rt_ballot(isMiss);
                 if (lane == 0) { runCnt[0][j * 4u + wave] = (uint32_t)__popcll(hb); runCnt[1][j * 4u + wave] = (uint32_t)__popcll(mb); }
             }
             lds_barrier();
@@ -1541,7 +1541,7 @@ __global__ __launch_bounds__(256, DEAL ? RT_SHADE_OCC : RT_SHADE_OCC + 1) void w
 #pragma unroll
             for (uint32_t j = 0; j < kShadeBatch; j++) {
                 const uint32_t c = (cls >> (2u * j)) & 3u;
-                const unsigned long long hb = __ballot(c == 1u), mb = __ballot(c == 2u);
+                const unsigned long long hb = rt_ballot(c == 1u), mb = rt_ballot(c == 2u);
                 if (c == 1u) perm[runCnt[0][j * 4u + wave] + (uint32_t)__popcll(hb & below)] = (uint16_t)(j * 256u + threadIdx.x);
                 if (c == 2u) perm[nHit + runCnt[1][j * 4u + wave] + (uint32_t)__popcll(mb & below)] = (uint16_t)(j * 256u + threadIdx.x);
             }

@@ -312,7 +312,7 @@ struct BvhCounters { uint32_t nodes, tris; uint32_t idleA = 0, idleB = 0; uint32
 // diagnostic build: lanes idle while the wave runs a traversal-loop body (first active lane counts)
 __device__ __forceinline__ void count_idle(uint32_t& acc)
 {
-    const unsigned long long m = __ballot(true);
+    const unsigned long long m = rt_ballot(true);
     if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) acc += 64u - (uint32_t)__popcll(m);
 }
 #else
@@ -814,10 +814,11 @@ __device__ __forceinline__ void trav_tri_step(Trav& T, const SceneView& s, const
 // live in scalar registers -- are the same for all lanes.
 template <class HS>
 __device__ __forceinline__ void trav_burst(Trav& T, const SceneView& s, const Ray& ray, HS& stack,
-                                           BvhCounters& cnt, int keep, uint32_t& uNodes, uint32_t& uTris)
+                                           BvhCounters& cnt, int keepIn, uint32_t& uNodes, uint32_t& uTris)
 {
+    const int keep = __builtin_amdgcn_readfirstlane(keepIn);   // the same in every lane: says so to the compiler, whose loop is then a scalar one
 #ifdef RT_LOOP_TIMERS
-    const bool leader = (int)(threadIdx.x & 63) == __builtin_ctzll(__ballot(true));
+    const bool leader = (int)(threadIdx.x & 63) == __builtin_ctzll(rt_ballot(true));
 #endif
     for (;;) {
 #ifdef RT_LOOP_TIMERS
@@ -825,18 +826,24 @@ __device__ __forceinline__ void trav_burst(Trav& T, const SceneView& s, const Ra
 #endif
         const bool wantNode = T.node >= 0 && T.node != kTravEnd;
         const bool wantTri = T.triCount != 0u || T.node < 0;
-        const int nNode = __popcll(__ballot(wantNode)), nTri = __popcll(__ballot(wantTri));
+        // the votes as lane masks of single compares, combined in scalar registers: the vote of a compound condition
+        // costs a select and a second compare per lane on top of the compares that make it
+        const unsigned long long mNode = rt_ballot(wantNode), mCount = rt_ballot(T.triCount != 0u), mLeaf = rt_ballot(T.node < 0);
+        const unsigned long long mTri = mCount | mLeaf;
+        // (counts of the two halves: the compiler knows a 64-bit count and then compares the two as 64-bit values, in the vector unit)
+        const uint32_t nNode = (uint32_t)__builtin_popcount((uint32_t)mNode) + (uint32_t)__builtin_popcount((uint32_t)(mNode >> 32));
+        const uint32_t nTri = (uint32_t)__builtin_popcount((uint32_t)mTri) + (uint32_t)__builtin_popcount((uint32_t)(mTri >> 32));
         // leave when most of the wave has finished: the finished lanes get shaded and re-armed
-        if (__popcll(__ballot(wantNode || wantTri)) < keep || nNode + nTri == 0) break;
-        if (nTri * RT_TRI_DEN >= nNode * RT_TRI_NUM) {
-            uTris += (uint32_t)__popcll(__ballot(T.triCount != 0u));
+        if ((mNode | mTri) == 0ull || (int)__popcll(mNode | mTri) < keep) break;
+        if (nTri * (uint32_t)RT_TRI_DEN >= nNode * (uint32_t)RT_TRI_NUM) {
+            uTris += (uint32_t)__popcll(mCount);
+#ifdef RT_LOOP_TIMERS
             if (wantTri) {
                 count_idle(cnt.idleB);
-#ifdef RT_LOOP_TIMERS
-                if ((int)(threadIdx.x & 63) == __builtin_ctzll(__ballot(true))) cnt.diagB++;
-#endif
-                trav_tri_step(T, s, ray, stack, cnt);
+                if ((int)(threadIdx.x & 63) == __builtin_ctzll(rt_ballot(true))) cnt.diagB++;
             }
+#endif
+            trav_tri_step(T, s, ray, stack, cnt);   // (a lane with no triangle pending does nothing in it)
 #ifdef RT_LOOP_TIMERS
             if (leader) cnt.idleB += (uint32_t)((clock64() - tl0) >> 4);
 #endif
@@ -845,7 +852,7 @@ __device__ __forceinline__ void trav_burst(Trav& T, const SceneView& s, const Ra
             if (wantNode) {
                 count_idle(cnt.idleA);
 #ifdef RT_LOOP_TIMERS
-                if ((int)(threadIdx.x & 63) == __builtin_ctzll(__ballot(true))) cnt.diagA++;
+                if ((int)(threadIdx.x & 63) == __builtin_ctzll(rt_ballot(true))) cnt.diagA++;
 #endif
                 node_step(s, T.br, T.bound, stack, T.sp, T.node);
                 trav_take_leaf(T, s, stack);
