@@ -1133,6 +1133,7 @@ __global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const R
     unsigned long long exhausted = 0ull;
     bool stripeOk = false, pendIssued = false;
     uint32_t pendC = 0;
+    uint32_t uNodeTests = 0, uNodeFetches = 0, uTris = 0;   // wave-uniform statistics (scalar registers): no vector work per step
     auto pick_stripe = [&]() -> bool {
         if (stripeOk && !(exhausted & (1ull << stripe))) return true;
         for (int k = 0; k < kWfStripes; k++) {
@@ -1175,7 +1176,9 @@ __global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const R
             ray.ox = o.x; ray.oy = o.y; ray.oz = o.z; ray.maxDist = o.w; ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
         }
         Trav T; trav_init(T, a.scene, ray); // a lane without a ray has bound -1: it enters no box and accepts no hit
-        if (rt_ballot(active) == 0ull) continue;
+        const unsigned long long activeMask = rt_ballot(active);
+        if (activeMask == 0ull) continue;
+        const uint32_t nActive = (uint32_t)__popcll(activeMask);
         bool overflow = false;
 #ifdef RT_PHASE_TIMERS
         const long long tk1 = clock64();
@@ -1192,18 +1195,14 @@ __global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const R
                     const uint4 N1 = reinterpret_cast<const uint4*>(np)[1], N2 = reinterpret_cast<const uint4*>(np)[2];
                     const int4 CH = reinterpret_cast<const int4*>(np)[3];
                     uint32_t k[4];
-                    node_test(T.br, N0, N1, N2, T.bound, k);
-                    st.bvh.nodes += active ? 1u : 0u;
-#if !defined(RT_PHASE_TIMERS) && !defined(RT_LOOP_TIMERS) && !defined(RT_UTIL_COUNTERS)
-                    st.bvh.idleA += active ? 1u : 0u;   // rt_stats.packet_node_tests / packet_node_fetches
-                    st.bvh.idleB += lane == 0 ? 1u : 0u;
-#endif
+                    bool kHit[4];
+                    node_test(T.br, N0, N1, N2, T.bound, k, kHit);
+                    uNodeTests += nActive; uNodeFetches++;
 #ifdef RT_PHASE_TIMERS
                     dbgNodes++; dbgSp = sp > dbgSp ? sp : dbgSp;
 #endif
                     // children some lane enters, ordered by the entry distances of the first lane that enters any
-                    const unsigned long long h0 = rt_ballot(k[0] != kMissKey), h1 = rt_ballot(k[1] != kMissKey),
-                                             h2 = rt_ballot(k[2] != kMissKey), h3 = rt_ballot(k[3] != kMissKey);
+                    const unsigned long long h0 = rt_ballot(kHit[0]), h1 = rt_ballot(kHit[1]), h2 = rt_ballot(kHit[2]), h3 = rt_ballot(kHit[3]);
                     const unsigned long long any = h0 | h1 | h2 | h3;
                     int h = 0;
                     if (any != 0ull) {
@@ -1241,7 +1240,7 @@ __global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const R
                     for (uint32_t q = 0; q < count; q++) {
                         const float4* tp = reinterpret_cast<const float4*>(a.scene.triLeaf + T.triBase + first + q);
                         const float4 A = tp[0], B = tp[1], C = tp[2];
-                        st.bvh.tris += active ? 1u : 0u;
+                        uTris += nActive;
                         trav_test_triangle(T, a.scene, A, B, C);
                     }
                     if (sp == 0) break;
@@ -1276,6 +1275,12 @@ __global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const R
             }
             if (tk2 - tk1 > (1ll << 20)) st.bvh.diagB += tk2 - tk1 > (1ll << 24) ? (1u << 20) : (tk2 - tk1 > (1ll << 22) ? (1u << 10) : 1u);
         }
+#endif
+    }
+    if (lane == 0) {
+        st.bvh.nodes += uNodeTests; st.bvh.tris += uTris;
+#if !defined(RT_PHASE_TIMERS) && !defined(RT_LOOP_TIMERS) && !defined(RT_UTIL_COUNTERS)
+        st.bvh.idleA += uNodeTests; st.bvh.idleB += uNodeFetches;   // rt_stats.packet_node_tests / packet_node_fetches
 #endif
     }
     flush_stats(a, st, wgCnt);

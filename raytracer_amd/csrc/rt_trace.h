@@ -281,8 +281,9 @@ __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elemen
 
 // tlo: distances below it are of no interest (0 in the hot kernels; the band walk of a ray whose closest hit is known
 // skips the boxes that end before it).
+// hit[c]: the compare behind key[c] != kMissKey, for callers that count or vote on it (a second compare per child otherwise)
 __device__ __forceinline__ void node_test(const BoxRay& b, const float4& N0, const uint4& N1, const uint4& N2, float bound,
-                                          uint32_t key[4], const float tlo = 0.0f)
+                                          uint32_t key[4], bool hit[4], const float tlo = 0.0f)
 {
     // N0 = ox oy oz sx | N1 = sy sz lox loy | N2 = loz hix hiy hiz
     const f2 ax = splat2(N0.w * b.ix), ay = splat2(__uint_as_float(N1.x) * b.iy), az = splat2(__uint_as_float(N1.y) * b.iz);
@@ -301,8 +302,9 @@ __device__ __forceinline__ void node_test(const BoxRay& b, const float4& N0, con
         const float tn1 = __builtin_fmaxf(__builtin_fmaxf(t0x.y, t0y.y), __builtin_fmaxf(t0z.y, tlo));
         const float tf0 = __builtin_fminf(__builtin_fminf(t1x.x, t1y.x), __builtin_fminf(t1z.x, bound));
         const float tf1 = __builtin_fminf(__builtin_fminf(t1x.y, t1y.y), __builtin_fminf(t1z.y, bound));
-        key[c] = tn0 <= tf0 ? __float_as_uint(tn0) : kMissKey;
-        key[c + 1] = tn1 <= tf1 ? __float_as_uint(tn1) : kMissKey;
+        hit[c] = tn0 <= tf0; hit[c + 1] = tn1 <= tf1;
+        key[c] = hit[c] ? __float_as_uint(tn0) : kMissKey;
+        key[c + 1] = hit[c + 1] ? __float_as_uint(tn1) : kMissKey;
     }
 }
 
@@ -348,6 +350,12 @@ struct Stack {
         if (h >= 3) push(sp, c2);
         if (h >= 2) push(sp, c1);
     }
+    __device__ __forceinline__ void push_far(int& sp, bool p1, bool p2, bool p3, uint32_t c1, uint32_t c2, uint32_t c3)
+    {
+        if (p3) push(sp, c3);
+        if (p2) push(sp, c2);
+        if (p1) push(sp, c1);
+    }
 };
 
 // LDS-only stack of the hot kernel: a push beyond kLdsStack entries is dropped and remembered; the
@@ -373,6 +381,17 @@ struct HotStackT {
         if (h >= 3) top[-3 * kBlock] = c2;
         if (h >= 4) top[-4 * kBlock] = c3;
         sp += h >= 2 ? h - 1 : 0;
+    }
+    // the same from the sorted keys' own verdicts (p1: a second child was hit, ...): farthest first, so c3 lowest
+    __device__ __forceinline__ void push_far(int& sp, bool p1, bool p2, bool p3, uint32_t c1, uint32_t c2, uint32_t c3)
+    {
+        if (sp + 3 > CAP) { dropped = dropped || p1; return; }
+        const int n = (int)p1 + (int)p2 + (int)p3;
+        uint32_t* top = lds + (sp + n) * kBlock;
+        if (p1) top[-1 * kBlock] = c1;
+        if (p2) top[-2 * kBlock] = c2;
+        if (p3) top[-3 * kBlock] = c3;
+        sp += n;
     }
 };
 using HotStack = HotStackT<kLdsStack>;
@@ -402,15 +421,17 @@ __device__ __forceinline__ void node_step(const SceneView& s, const BoxRay& br, 
     const uint4 N1 = reinterpret_cast<const uint4*>(np)[1], N2 = reinterpret_cast<const uint4*>(np)[2];
     const int4 CH = reinterpret_cast<const int4*>(np)[3];
     uint32_t k[4];
-    node_test(br, N0, N1, N2, bound, k, tlo);
+    bool hit[4];
+    node_test(br, N0, N1, N2, bound, k, hit, tlo);
     int32_t c0 = CH.x, c1 = CH.y, c2 = CH.z, c3 = CH.w;
-    const int h = (k[0] != kMissKey) + (k[1] != kMissKey) + (k[2] != kMissKey) + (k[3] != kMissKey);
+    (void)hit;
     cmp_swap(k[0], k[1], c0, c1); cmp_swap(k[2], k[3], c2, c3);
     cmp_swap(k[0], k[2], c0, c2); cmp_swap(k[1], k[3], c1, c3);
     cmp_swap(k[1], k[2], c1, c2);
-    stack.push_far(sp, h, (uint32_t)c1, (uint32_t)c2, (uint32_t)c3);
+    // sorted, the misses last: how many children were hit reads off the keys (no count to keep)
+    stack.push_far(sp, k[1] != kMissKey, k[2] != kMissKey, k[3] != kMissKey, (uint32_t)c1, (uint32_t)c2, (uint32_t)c3);
     node = c0;
-    if (h == 0) node = (int32_t)stack.pop(sp);
+    if (k[0] == kMissKey) node = (int32_t)stack.pop(sp);
 }
 
 // The triangles no box can stand for (SceneView::thin; rt_commit.hip, thin_kernel).  A ray can only "hit" one where all three
