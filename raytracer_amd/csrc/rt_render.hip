@@ -953,12 +953,10 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
 {
     __builtin_assume(level >= 1);   // the camera rays go through the packet kernel (launch_render_wf)
     __shared__ uint32_t ldsStack[kWfStack * kBlock];
-    __shared__ uint32_t poolSlot[kBlock];
     __shared__ float4 poolO[kBlock], poolD[kBlock];   // the block of rays being handed out (`cur` below), one entry per lane
     __shared__ uint32_t wgCnt[8];
     HotStackT<kWfStack> stack; stack.lds = ldsStack + threadIdx.x; stack.dropped = false;
     const int lane = threadIdx.x & 63;
-    uint32_t* slotx = poolSlot + (threadIdx.x & ~63);
     float4* curO = poolO + (threadIdx.x & ~63);
     float4* curD = poolD + (threadIdx.x & ~63);
     LaneStats st; st.rays = 0; st.slow = 0; st.triBrute = 0; st.hits = 0; st.bvh.nodes = 0; st.bvh.tris = 0;
@@ -971,7 +969,8 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
     // level's launch went into the dependent chain atomic -> queue entry -> ray at refill time.
     const uint32_t waveId = blockIdx.x * 4u + (threadIdx.x >> 6);
     uint32_t stripe = waveId % kWfStripes, stripeCnt = 0;   // wave-uniform
-    unsigned long long exhausted = 0ull, poolMask = 0ull;
+    unsigned long long exhausted = 0ull;
+    uint32_t poolStart = 0, poolEnd = 0;   // the block's entries not yet handed out: they go in order (no holes past the camera rays), so a range says it all
     bool pendIssued = false, nxtHas = false, noMore = false, have = false;
     uint32_t pendC = 0;                 // lane 0: cursor value returned by the pending atomic
     uint32_t cBase = 0, nBase = 0, nCount = 0;   // wave-uniform: hit-array position of a block's first entry, entries in the block (no holes past the camera rays)
@@ -1064,31 +1063,28 @@ __global__ __launch_bounds__(256, RT_WF_OCC) void wf_trace_kernel(const RenderAr
         bool fresh = false;   // the lane took a ray: its traversal is set up once, behind the loop (inside it the whole traversal
                               // state would have to be merged at every turn: ninety register copies per refill)
         while (need != 0ull) {
-            if (poolMask == 0ull) {
+            if (poolStart == poolEnd) {
                 if (!nxtHas) { noMore = true; break; }
                 curO[lane] = nO; curD[lane] = nD; cBase = nBase;
-                poolMask = nCount >= 64u ? ~0ull : (1ull << nCount) - 1ull;
+                poolStart = 0u; poolEnd = nCount;
                 load_next();
-                if (poolMask == 0ull) continue;
+                if (poolEnd == 0u) continue;
             }
-            // the k-th needing lane takes the k-th live pool entry
-            const unsigned long long below = (1ull << lane) - 1ull;
-            if ((poolMask >> lane) & 1ull) slotx[__popcll(poolMask & below)] = (uint32_t)lane;
-            const int rank = __popcll(need & below);
-            const int avail = __popcll(poolMask);
-            const bool want = (need >> lane) & 1ull;
+            // the k-th needing lane takes the k-th entry of what is left of the block
+            const uint32_t rank = (uint32_t)__popcll(need & ((1ull << lane) - 1ull));
+            const uint32_t avail = poolEnd - poolStart;
+            const bool take = ((need >> lane) & 1ull) && rank < avail;
             __builtin_amdgcn_wave_barrier();
-            const int src = (want && rank < avail) ? (int)slotx[rank] : lane;
-            __builtin_amdgcn_wave_barrier();
-            if (want && rank < avail) {
+            if (take) {
+                const uint32_t src = poolStart + rank;
                 const float4 o = curO[src], d = curD[src];
                 ray.ox = o.x; ray.oy = o.y; ray.oz = o.z; ray.maxDist = o.w; ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
-                hitPos = cBase + (uint32_t)src;
+                hitPos = cBase + src;
                 have = true; fresh = true;
             }
-            // the entries handed out are the pool's first popc(taken) live ones
-            const int taken = __popcll(rt_ballot(want && rank < avail));
-            poolMask = rt_ballot(((poolMask >> lane) & 1ull) && __popcll(poolMask & below) >= taken);
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t wanted = (uint32_t)__popcll(need);
+            poolStart += wanted < avail ? wanted : avail;
             need = rt_ballot(!have && !noMore);
         }
         if (fresh) trav_begin(T, a.scene, ray, stack);
