@@ -1192,7 +1192,7 @@ __global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const R
                     const int4 CH = reinterpret_cast<const int4*>(np)[3];
                     uint32_t k[4];
                     bool kHit[4];
-                    node_test(T.br, N0, N1, N2, T.bound, k, kHit);
+                    node_test<false>(T.br, N0, N1, N2, T.bound, k, kHit);   // k: entry distances, valid where kHit
                     uNodeTests += nActive; uNodeFetches++;
 #ifdef RT_PHASE_TIMERS
                     dbgNodes++; dbgSp = sp > dbgSp ? sp : dbgSp;
@@ -1208,7 +1208,7 @@ __global__ __launch_bounds__(256, RT_PK_OCC) void wf_trace_packet_kernel(const R
 #pragma unroll
                         for (int c = 0; c < 4; c++) {
                             const uint32_t kr = (uint32_t)__builtin_amdgcn_readlane((int)k[c], rep);
-                            ks[c] = hm[c] == 0ull ? kMissKey : (kr == kMissKey ? 0xFFFFFFFEu : kr);
+                            ks[c] = hm[c] == 0ull ? kMissKey : (((hm[c] >> rep) & 1ull) == 0ull ? 0xFFFFFFFEu : kr);   // some lane enters, the ordering lane does not: last of the entered
                             h += hm[c] != 0ull;
                             cs[c] = __builtin_amdgcn_readfirstlane(cs[c]);
                         }

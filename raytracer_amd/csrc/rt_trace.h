@@ -282,6 +282,7 @@ __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elemen
 // tlo: distances below it are of no interest (0 in the hot kernels; the band walk of a ray whose closest hit is known
 // skips the boxes that end before it).
 // hit[c]: the compare behind key[c] != kMissKey, for callers that count or vote on it (a second compare per child otherwise)
+template <bool KEYS = true>
 __device__ __forceinline__ void node_test(const BoxRay& b, const float4& N0, const uint4& N1, const uint4& N2, float bound,
                                           uint32_t key[4], bool hit[4], const float tlo = 0.0f)
 {
@@ -303,8 +304,12 @@ __device__ __forceinline__ void node_test(const BoxRay& b, const float4& N0, con
         const float tf0 = __builtin_fminf(__builtin_fminf(t1x.x, t1y.x), __builtin_fminf(t1z.x, bound));
         const float tf1 = __builtin_fminf(__builtin_fminf(t1x.y, t1y.y), __builtin_fminf(t1z.y, bound));
         hit[c] = tn0 <= tf0; hit[c + 1] = tn1 <= tf1;
-        key[c] = hit[c] ? __float_as_uint(tn0) : kMissKey;
-        key[c + 1] = hit[c + 1] ? __float_as_uint(tn1) : kMissKey;
+        if (KEYS) {
+            key[c] = hit[c] ? __float_as_uint(tn0) : kMissKey;
+            key[c + 1] = hit[c + 1] ? __float_as_uint(tn1) : kMissKey;
+        } else {   // the entry distances as they are: the packet kernel orders the children by one lane's, read with that lane's verdicts
+            key[c] = __float_as_uint(tn0); key[c + 1] = __float_as_uint(tn1);
+        }
     }
 }
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# one counter pass of one workload per library build, wf_trace's launches only: tools/pmc_one.sh "COUNTERS" "bench args" lib1.so lib2.so ... ("default" = the product build)
+# one counter pass of one workload per library build, the launches of one kernel (KERNEL=substring, default wf_trace_kernel): tools/pmc_one.sh "COUNTERS" "bench args" lib1.so lib2.so ... ("default" = the product build)
 ctrs=$1; extra=$2; shift 2
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -20,7 +20,7 @@ for r in rows:
 byk=collections.defaultdict(list)
 for (k,d),v in acc.items(): byk[k].append((int(d),v))
 for k,l in byk.items():
-    if "wf_trace_kernel" not in k: continue
+    if "${KERNEL:-wf_trace_kernel}" not in k: continue
     l.sort()
     for d,v in l[-3:]:
         print("  ", k, d, " ".join("%s %.4g"%(a,b) for a,b in sorted(v.items())))
