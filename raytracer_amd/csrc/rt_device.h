@@ -33,6 +33,27 @@ constexpr int kBlock = 256;        // workgroup size of every tracing kernel
 constexpr int kCounterSlots = 256; // statistics counters are striped over this many 128-byte lines
 constexpr int kCounterStride = 16; // u64 per slot
 
+// Unsigned division by a launch constant as a multiplication (Granlund & Montgomery 1994, figure 4.1: exact for every
+// 32-bit n and every d >= 1): a 32-bit division by a run-time value is some thirty vector instructions, three of them at
+// quarter rate, and wf_gen did three per sample.
+struct FastDiv { uint32_t m, s1, s2; };
+inline FastDiv make_fast_div(uint32_t d)
+{
+    FastDiv f; f.m = 1u; f.s1 = 0u; f.s2 = 0u;
+    if (d <= 1u) return f;                       // n / 1: t = 0, q = n
+    uint32_t L = 0; while ((1ull << L) < (unsigned long long)d) L++;   // ceil(log2 d)
+    f.m = (uint32_t)((((1ull << L) - d) << 32) / d + 1ull);
+    f.s1 = 1u; f.s2 = L - 1u;
+    return f;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv& f)
+{
+    const uint32_t t = __umulhi(f.m, n);
+    return (t + ((n - t) >> f.s1)) >> f.s2;
+}
+#endif
+
 // 48 B: one world-space triangle, three 16-byte loads.  Two arrays of these exist: `triRef`
 // in reference order (object, mesh, triangle: index = gid) and `triLeaf` in BVH leaf order.
 struct TriIsect {
@@ -221,6 +242,8 @@ struct RenderArgs {
     // bands bandFirst, bandFirst + bandStride, ... are rendered; the pipeline's tile rows count through those bands
     // only (tiles8Y = owned bands * bandTileRows).  bandTileRows == 0: the whole rectangle.
     int32_t bandTileRows, bandFirst, bandStride;
+    // divisions of the wavefront pipeline by its three launch constants (launch_render_wf fills them in; fast_div)
+    FastDiv divSpp, divTilesX, divBandRows;
 };
 
 } // namespace rt

@@ -838,9 +838,10 @@ __device__ __forceinline__ size_t wf_out_index(uint32_t pix, uint32_t sidx, uint
 __device__ __forceinline__ bool wf_pixel(const RenderArgs& a, const WfBufs& w, uint32_t pix, int& x, int& y)
 {
     const uint32_t tile = w.tileBegin + (pix >> 6) * w.tileStride, in = pix & 63u;
-    uint32_t row = tile / (uint32_t)a.tiles8X;
+    const uint32_t row0 = fast_div(tile, a.divTilesX), col = tile - row0 * (uint32_t)a.tiles8X;
+    uint32_t row = row0;
     if (a.bandTileRows > 0) { // row counts through this call's bands only: band k of the call is band bandFirst + k * bandStride of the rectangle
-        const uint32_t k = row / (uint32_t)a.bandTileRows, in_band = row - k * (uint32_t)a.bandTileRows;
+        const uint32_t k = fast_div(row, a.divBandRows), in_band = row - k * (uint32_t)a.bandTileRows;
         row = ((uint32_t)a.bandFirst + k * (uint32_t)a.bandStride) * (uint32_t)a.bandTileRows + in_band;
     }
 #ifndef RT_TILE_ORDER
@@ -853,7 +854,7 @@ __device__ __forceinline__ bool wf_pixel(const RenderArgs& a, const WfBufs& w, u
 #else
     const uint32_t px = in & 7u, py = in >> 3;
 #endif
-    x = a.x0 + (int)(tile % (uint32_t)a.tiles8X) * 8 + (int)px;
+    x = a.x0 + (int)col * 8 + (int)px;
     y = a.y0 + (int)row * 8 + (int)py;
     return x < a.x1 && y < a.y1;
 }
@@ -888,7 +889,7 @@ __global__ __launch_bounds__(256) void wf_gen_kernel(const RenderArgs a, const W
     bool traced = false;
     if (i < w.nSlots) {
         const uint32_t spp = a.sampleCount;
-        const uint32_t pix = i / spp, sidx = i - pix * spp;
+        const uint32_t pix = fast_div(i, a.divSpp), sidx = i - pix * spp;
         int x, y;
         if (wf_pixel(a, w, pix, x, y)) {
             uint32_t seed = sample_seed(a, x, y, sidx);
@@ -1386,7 +1387,7 @@ __device__ __forceinline__ void shade_entry(const RenderArgs& a, const WfBufs& w
     const float4 aB = level == 0 ? make_float4(1.0f, 1.0f, 1.0f, 0.0f) : w.accB[pin];
     o.slot = level == 0 ? wf_level0_slot(stripe, off) : __float_as_uint(aB.w);
     const uint32_t spp = a.sampleCount;
-    const uint32_t pix = o.slot / spp, sidx = o.slot - pix * spp;
+    const uint32_t pix = fast_div(o.slot, a.divSpp), sidx = o.slot - pix * spp;
     Ray ray; ray.ox = ray.oy = ray.oz = 0.0f; ray.maxDist = 0.0f; ray.dx = d.x; ray.dy = d.y; ray.dz = d.z;
     uint32_t seed = __float_as_uint(d.w), checksum = __float_as_uint(aO.w);
     PathAcc acc; acc.ox = aO.x; acc.oy = aO.y; acc.oz = aO.z; acc.bx = aB.x; acc.by = aB.y; acc.bz = aB.z;
@@ -1635,7 +1636,7 @@ __global__ __launch_bounds__(256) void wf_redo_kernel(const RenderArgs a, const 
         for (uint32_t step = kWfStripes / 2; step > 0; step >>= 1)
             if (listBase[ls + step] <= item) ls += step;
         const uint32_t slot = w.redoSlots[(size_t)ls * w.subCap + (item - listBase[ls])];
-        const uint32_t pix = slot / spp, sidx = slot - pix * spp;
+        const uint32_t pix = fast_div(slot, a.divSpp), sidx = slot - pix * spp;
         int x, y;
         wf_pixel(a, w, pix, x, y);
         uint32_t seed = sample_seed(a, x, y, sidx), checksum = 0;
@@ -1711,6 +1712,8 @@ void launch_render_wf(const RenderArgs& a, const WfLanes& L, int numCUs, hipStre
     RenderArgs b = a;
     b.tiles8X = (a.x1 - a.x0 + 7) / 8;
     b.tiles8Y = wf_tile_rows(a);
+    b.divSpp = make_fast_div(a.sampleCount); b.divTilesX = make_fast_div((uint32_t)b.tiles8X);
+    b.divBandRows = make_fast_div(a.bandTileRows > 0 ? (uint32_t)a.bandTileRows : 1u);
     b.pixelList = nullptr; b.pixelCount = nullptr;
     const uint32_t nTiles = (uint32_t)b.tiles8X * (uint32_t)b.tiles8Y;
     if (nTiles == 0) return;
