@@ -111,6 +111,20 @@ def test_product_never_imports_the_oracle():
                 assert "oracle_py" not in txt and "liboracle" not in txt and "rt_oracle.h" not in txt, f
 
 
+def test_launch_constant_divisions(tmp_path):
+    """The wavefront kernels divide by their launch constants (samples per pixel, tiles per row, rows per band) with a
+    multiply and two shifts (csrc/rt_device.h, make_fast_div / fast_div): the constants the host code makes, with the device
+    formula restated on host integers, against n / d for every divisor to 200 000, the powers of two and their neighbours up
+    to 2^31 and two million random pairs (tests/cpp/fast_div_check.cpp, built with hipcc here: the header is HIP's)."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    exe = str(tmp_path / "fast_div_check")
+    subprocess.check_call([hipcc, "-O2", "-std=c++17", "--offload-arch=gfx950", os.path.join(ROOT, "tests", "cpp", "fast_div_check.cpp"), "-o", exe])
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and " bad 0" in p.stdout, p.stdout
+
+
 def test_band_and_frame_partitions():
     for world in (1, 2, 3, 8):
         rows = np.zeros(1080, int)
