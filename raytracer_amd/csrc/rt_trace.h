@@ -525,7 +525,7 @@ __device__ __forceinline__ void cull_lookup(const SceneView& s, const Ray& ray, 
 
 // Exact emulation of :247-265 restricted to the objects that have an accepted hit with
 // t <= limit (objects beyond cannot change the outcome).
-__device__ __noinline__ Hit trace_bvh_exact(const SceneView& s, Ray& ray, const TriRay& q, const BoxRay& br,
+__device__ __noinline__ Hit trace_bvh_exact(const SceneView s, Ray& ray, const TriRay& q, const BoxRay& br,
                                             float limit, Stack& stack, BvhCounters& cnt)
 {
     Hit best; best.t = FLT_MAX; best.gid = kNoHit; best.b0 = best.b1 = best.b2 = 0.0f;
@@ -853,7 +853,9 @@ __device__ __forceinline__ void trav_burst(Trav& T, const SceneView& s, const Ra
         const bool wantNode = T.node >= 0 && T.node != kTravEnd;
         const bool wantTri = T.triCount != 0u || T.node < 0;
         // the votes as lane masks of single compares, combined in scalar registers: the vote of a compound condition
-        // costs a select and a second compare per lane on top of the compares that make it
+        // costs a select and a second compare per lane on top of the compares that make it.  (The vote on a leaf parked in
+        // `node` is not redundant with the one on pending triangles: an empty slot's leaf -- reached by a ray with non-finite
+        // components, whose box tests all pass -- leaves the pending range empty, and the lane moves on through a triangle step.)
         const unsigned long long mNode = rt_ballot(wantNode), mCount = rt_ballot(T.triCount != 0u), mLeaf = rt_ballot(T.node < 0);
         const unsigned long long mTri = mCount | mLeaf;
         // (counts of the two halves: the compiler knows a 64-bit count and then compares the two as 64-bit values, in the vector unit)
